@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path: formula-1 scene, 2000x1200, depth 8 (the 8192-spp frame in slices).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one pass of the path kernel over every pixel of the frame for `--spp-per-step` further
+samples of the 8192-spp frame (the frame is 8192/spp-per-step such passes; nothing is cached
+between steps: each step traces new sample indices).  With N > 1 (launched by torch.distributed.run,
+one process per GPU) the scene is replicated, every rank traces its own sample range in each step
+(weak scaling) and the accumulation buffers are summed onto rank 0 with one RCCL reduce per step,
+inside the timed region.  Rank 0 prints ONE JSON line.
+
+value      = whole-job Mrays/s: closest-hit queries (device counter) of all ranks / max-over-ranks time.
+roofline   = algorithmic bytes per launch / mean kernel time (HIP events on the launch stream), against 8 TB/s HBM.
+             bytes per ray = 32*box_tests + 36*triangle_tests + 100*shaded + 16*texture_fetches, measured per
+             ray by an instrumented pass of the same kernel, plus 24 B per pixel per launch for the buffer.
+cpu_baseline = the CPU oracle (a port of upstream's logic, OpenMP) on a bounded sample of the same
+             workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x5EED0001
+FRAME_SPP = 8192
+HBM_PEAK_GBPS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16, help="semantic batch (upstream's <batch_size>)")
+    ap.add_argument("--scene", default="formula1", choices=["formula1", "formula1_glass", "shuttle", "luyu"])
+    ap.add_argument("--width", type=int, default=2000)
+    ap.add_argument("--height", type=int, default=1200)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the bounded CPU-baseline run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-image", default="")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytrace_amd import capi, scene
+    from raytrace_amd.dist import reduce_to_root
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes; running 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- scene (replicated on every rank) ----
+    t0 = time.time()
+    if args.scene == "formula1":
+        asm = scene.formula1(args.width, args.height, FRAME_SPP, detail=args.detail)
+    elif args.scene == "formula1_glass":
+        asm = scene.formula1(args.width, args.height, FRAME_SPP, glass=True, detail=args.detail)
+    elif args.scene == "shuttle":
+        asm = scene.shuttle(args.width, args.height, FRAME_SPP, detail=args.detail)
+    else:
+        asm = scene.luyu(args.width, args.height, FRAME_SPP)
+    cfg = asm.config
+    objs = scene.finalize(asm)
+    t_build = time.time() - t0
+    ctx = capi.Context(local_rank)
+    ctx.upload_scene(objs, asm.materials, asm.textures)
+    stats = ctx.scene_stats()
+    ctx.init_randstate(SEED, cfg.width, cfg.height)
+    ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+    npix = cfg.width * cfg.height
+    if rank == 0:
+        log(f"scene {args.scene}: {stats['triangles']} triangles, {stats['objects']} objects, "
+            f"{stats['device_bytes'] / 1e6:.1f} MB packed, built in {t_build:.1f}s")
+
+    accum = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+    staging = torch.zeros_like(accum) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    spp = args.spp_per_step
+    assert spp % args.batch == 0, "--spp-per-step must be a multiple of --batch"
+
+    def first_sample(step):
+        # step s covers global samples [s*world*spp, (s+1)*world*spp); rank r takes the r-th slice of it
+        return (step * world + rank) * spp
+
+    def run_step(step, ev=None):
+        if ev:
+            ev[0].record()
+        ctx.raytrace(npix, first_sample(step), spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
+                     accum.data_ptr(), stream)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            staging.copy_(accum)
+            reduce_to_root(staging, 0)
+
+    # ---- instrumented pass: per-ray work mix of this kernel on this workload (not timed) ----
+    ctx.set_option(capi.OPT_COUNTERS, 1)
+    ctx.reset_counters()
+    scratch = torch.zeros_like(accum)
+    inst_spp = min(spp, 32)
+    ctx.raytrace(npix, first_sample(0), inst_spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
+                 scratch.data_ptr(), stream)
+    c = ctx.counters()
+    del scratch
+    rays_i = max(1, c[capi.CNT_RAYS])
+    mix = {"box_tests_per_ray": c[capi.CNT_BOX_TESTS] / rays_i, "tri_tests_per_ray": c[capi.CNT_TRI_TESTS] / rays_i,
+           "shaded_per_ray": c[capi.CNT_SHADED] / rays_i, "tex_per_ray": c[capi.CNT_TEX_FETCHES] / rays_i,
+           "rays_per_path": c[capi.CNT_RAYS] / max(1, c[capi.CNT_PATHS])}
+    bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
+    ctx.set_option(capi.OPT_COUNTERS, 0)
+
+    # ---- warmup ----
+    for s in range(args.warmup):
+        run_step(s)
+    torch.cuda.synchronize()
+    ctx.reset_counters()
+
+    # ---- timed region ----
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        run_step(args.warmup + k, events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    cnt = ctx.counters()
+    rays = float(cnt[capi.CNT_RAYS])
+    paths = float(cnt[capi.CNT_PATHS])
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays, paths], dtype=torch.float64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays, paths = float(r[0].item()), float(r[1].item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / max(1, args.steps)
+        mrays = rays / elapsed / 1e6
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+        rays_per_launch = float(cnt[capi.CNT_RAYS]) / max(1, args.steps)
+        algo_bytes = rays_per_launch * bytes_per_ray + 24.0 * npix
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (procedural stand-in for the formula-1 OBJ, which upstream does not ship)",
+            "config": {"workload": f"scene_{args.scene} textured, {cfg.width}x{cfg.height}, depth {cfg.max_depth}, rr {cfg.russian_roulette}, "
+                                   f"{FRAME_SPP}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
+                       "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
+                       "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU"},
+            "seconds_per_frame": round(ms_per_step * 1e-3 * FRAME_SPP / (spp * world), 3),
+            "mpaths_per_s": round(paths / elapsed / 1e6, 2),
+            "kernel_ms_mean": round(k_ms, 3),
+            "work_mix": {k: round(v, 4) for k, v in mix.items()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "bytes_per_ray": round(bytes_per_ray, 1), "kernel": "path_kernel"},
+            "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(asm, objs, args)
+        if args.save_image:
+            save_image(ctx, accum, cfg, (args.warmup + args.steps) * spp * world, args.save_image)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(asm, objs, args):
+    """The oracle (a CPU port of upstream's path logic; upstream's own cpu-rt is a different renderer and cannot be
+    built here) on the same scene and frame size for --cpu-spp samples per pixel, all host threads OpenMP gives us."""
+    from oracle import oracle as orc
+    sc = orc.Scene(objs, asm.materials, asm.textures)
+    p = orc.make_params(asm.config, SEED, args.batch)
+    t0 = time.perf_counter()
+    _, cnt = sc.render(p, 0, args.cpu_spp)
+    dt = time.perf_counter() - t0
+    return {"value": round(float(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"same scene, {asm.config.width}x{asm.config.height}, {args.cpu_spp} spp ({int(cnt[0])} rays in {dt:.1f}s)",
+            "seconds_per_frame_extrapolated": round(dt * FRAME_SPP / args.cpu_spp, 1)}
+
+
+def save_image(ctx, accum, cfg, spp_done, path):
+    from PIL import Image
+    img = accum.clone()
+    ctx.post_process(cfg.width * cfg.height, spp_done, cfg.gamma, img.data_ptr())
+    ctx.synchronize()
+    a = img.cpu().numpy().reshape(cfg.height, cfg.width, 3)[::-1]
+    Image.fromarray(np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)).save(path)
+
+
+if __name__ == "__main__":
+    main()

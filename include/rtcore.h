@@ -1,0 +1,200 @@
+/* rtcore.h -- C ABI of the MI355X path-tracing core (librtcore.so).
+ *
+ * The upstream renderer (s7a9/RayTrace) has no plugin ABI; its seam is the set
+ * of C++ free functions that Worker/SceneLoader call into the .cu files.  Each
+ * entry point below names the upstream declaration it replaces (file:line,
+ * relative to the upstream repository root).  Only plain pointers, sizes and
+ * PODs cross this boundary.  Every function returns 0 on success and a
+ * negative rt_status on failure; rt_last_error() gives the message of the last
+ * failure on the calling thread.  Each call selects its context's device
+ * itself, so a context may be driven from any one thread at a time.
+ *
+ * Floating-point contract: IEEE binary32, no FMA contraction, correctly
+ * rounded divide/sqrt -- identical on the host halves and in the kernels, so
+ * that hit records are bit-reproducible.
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTCORE_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument */
+    RT_ERR_DEVICE = -2,       /* HIP runtime error */
+    RT_ERR_NO_SCENE = -3,     /* call needs rt_upload_scene first */
+    RT_ERR_NO_CAMERA = -4,    /* call needs rt_setup_raytrace first */
+    RT_ERR_CAPACITY = -5      /* caller buffer too small */
+} rt_status;
+
+/* ---- PODs in the upstream host layout (so upstream arrays pass unchanged) ---- */
+
+typedef struct rt_float3 { float x, y, z; } rt_float3;
+
+/* include/primitives.cuh:22-26 -- CUDA float2 is 8-byte aligned, hence the alignment. */
+typedef struct rt_vertex {
+    rt_float3 position;
+    rt_float3 normal;
+    float texcoord[2];
+} __attribute__((aligned(8))) rt_vertex;                     /* 32 bytes */
+
+/* include/primitives.cuh:28-31 */
+typedef struct rt_triangle {
+    int32_t material_id;
+    rt_vertex v[3];
+} rt_triangle;                                               /* 104 bytes */
+
+/* include/bvh.h:62-65 (bool is_leaf; AABB box; int left, right) */
+typedef struct rt_bvh_node {
+    uint8_t is_leaf;
+    uint8_t pad_[3];
+    rt_float3 box_min;
+    rt_float3 box_max;
+    int32_t left, right;
+} rt_bvh_node;                                               /* 36 bytes */
+
+/* include/renderobject.cuh:10-15, with HOST pointers */
+typedef struct rt_object {
+    const rt_triangle* triangles;
+    const rt_bvh_node* bvh;
+    int32_t n_triangles;
+    int32_t n_bvh_nodes;
+} rt_object;
+
+/* include/material.cuh:10-26; the CUDA array/texture handles become an index
+ * into the texture table passed to rt_upload_scene (-1 = untextured). */
+enum { RT_MAT_NONE = 0, RT_MAT_LIGHT, RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_REFRACTIVE, RT_MAT_REFLECTIVE };
+typedef struct rt_material {
+    int32_t type;
+    rt_float3 albedo;
+    float optical_density;
+    float metal_fuzz;
+    int32_t texture;
+    int32_t pad_;
+} rt_material;                                               /* 32 bytes */
+
+/* csrc/sceneloader.cpp:223-252: RGBA8, row 0 = bottom row (already flipped). */
+typedef struct rt_texture {
+    const uint8_t* rgba;
+    int32_t width, height;
+} rt_texture;
+
+/* include/transform.cuh:10-14 */
+typedef struct rt_transform {
+    rt_float3 scale;
+    rt_float3 translation;
+    rt_float3 rotation;       /* degrees */
+} rt_transform;
+
+typedef struct rt_context rt_context;
+
+/* counters returned by rt_get_counters */
+enum {
+    RT_CNT_RAYS = 0,          /* closest-hit queries (one per depth-loop iteration, cuda/raytrace.cu:213-219) */
+    RT_CNT_BOX_TESTS,         /* AABB slab tests */
+    RT_CNT_TRI_TESTS,         /* Moller-Trumbore tests */
+    RT_CNT_SHADED,            /* hits that reached triangle_interpolate */
+    RT_CNT_TEX_FETCHES,       /* bilinear texture fetches */
+    RT_CNT_PATHS,             /* camera samples finished */
+    RT_CNT_COUNT = 8
+};
+
+/* options for rt_set_option */
+enum {
+    RT_OPT_COUNTERS = 1,      /* 0 = rays/paths only (default), 1 = also box/triangle/shade/texture counts */
+    RT_OPT_XCD_REMAP = 2      /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
+};
+
+const char* rt_last_error(void);
+int rt_abi_version(void);
+
+/* ---- host halves of the path ---- */
+
+/* Replaces vrt::build_bvh (include/bvh.h:76, csrc/bvh.cpp:77-98): median split on
+ * the longest centroid axis, <=2 triangles per leaf, post-order array, root last.
+ * Returns the node count (>0), or RT_ERR_CAPACITY if capacity < count
+ * (2*n_triangles always suffices). */
+int rt_build_bvh(const rt_triangle* triangles, int n_triangles, rt_bvh_node* nodes_out, int capacity);
+
+/* Replaces vrt::apply_transform (include/transform.cuh:16, cuda/transforms.cu:32-53):
+ * position = R*(position*scale) + translation, normal = R*normal, in place. */
+int rt_apply_transform(const rt_transform* transform, rt_triangle* triangles, int n_triangles);
+
+/* ---- context ---- */
+int rt_create(int device_id, rt_context** out);
+int rt_destroy(rt_context* ctx);
+int rt_set_option(rt_context* ctx, int option, int value);
+
+/* Replaces the uploads in SceneLoader::load_scene (csrc/sceneloader.cpp:336-399):
+ * takes the host arrays in upstream layout, re-packs them for 64-lane fetches
+ * and copies them to the context's device.  May be called again to replace the scene. */
+int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects,
+                    const rt_material* materials, int n_materials,
+                    const rt_texture* textures, int n_textures);
+
+/* ---- the render calls Worker::render_ makes (csrc/worker.cpp:64-97) ---- */
+
+/* Replaces vrt::init_randstate (include/camera.cuh:9, cuda/camera.cu:15-21).  The
+ * generator is counter based, so there is no state array; this records the seed
+ * (upstream uses time(0)) and the frame size. */
+int rt_init_randstate(rt_context* ctx, uint64_t seed, int width, int height);
+
+/* Replaces vrt::setup_raytrace (include/camera.cuh:11-16, cuda/camera.cu:43-64):
+ * builds the camera frame on the host.  Primary rays are regenerated inside the
+ * path kernel from (pixel, batch index), so no Ray array is written. */
+int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera_pos[3],
+                      const float camera_dir[3], const float camera_up[3], float fov_radians);
+
+/* Replaces vrt::raytrace (include/raytrace.cuh:8-15, cuda/raytrace.cu:197-287) and the
+ * batch loop around it (csrc/worker.cpp:71-91).  Traces global samples
+ * [first_sample, first_sample + spp) of every pixel and adds them to
+ * d_output (device, float[3*n_pixel], row-major, y up).  `semantic_batch` is
+ * upstream's <batch_size>: samples k*B .. k*B+B-1 share one jittered primary
+ * ray and are summed before being added to the buffer.  first_sample must be a
+ * multiple of semantic_batch.  Asynchronous on `stream` (a hipStream_t, may be null). */
+int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch,
+                int max_depth, const float ambient[3], float russian_roulette,
+                float* d_output, void* stream);
+
+/* Replaces vrt::post_process (include/raytrace.cuh:17, cuda/raytrace.cu:249-297):
+ * c /= spp, clamp to [0,1], c = pow(c, 1/gamma), in place.  Asynchronous on `stream`
+ * (upstream synchronises; callers that need that call rt_synchronize). */
+int rt_post_process(rt_context* ctx, int n_pixels, int spp, float gamma, float* d_output, void* stream);
+
+/* ---- parity / diagnostics entry points (no upstream counterpart: upstream has no tests) ---- */
+
+/* The Ray array upstream's setup_raytrace_kernel would have written for semantic
+ * batch `batch_index` (cuda/camera.cu:23-41): d_rays = float[6*width*height]. */
+int rt_primary_rays(rt_context* ctx, uint32_t batch_index, float* d_rays, void* stream);
+
+/* Closest hit of explicit rays (the object loop of cuda/raytrace.cu:214-219):
+ * d_rays = float[6*n] (origin, direction); outputs per ray: object index, triangle
+ * index within that object (both -1 on a miss), t (inf on a miss), u, v.  d_u/d_v may be null. */
+int rt_closest_hit(rt_context* ctx, int n_rays, const float* d_rays, int32_t* d_object,
+                   int32_t* d_triangle, float* d_t, float* d_u, float* d_v, void* stream);
+
+int rt_get_counters(rt_context* ctx, uint64_t out[RT_CNT_COUNT]);   /* synchronises the device */
+int rt_reset_counters(rt_context* ctx);
+
+/* Scene statistics after upload: out[0]=triangles, [1]=packed inner nodes, [2]=max stack depth,
+ * [3]=device bytes of the packed scene, [4]=objects. */
+int rt_scene_stats(rt_context* ctx, uint64_t out[8]);
+
+/* ---- device-memory helpers for callers that do not link the HIP runtime ---- */
+int rt_device_alloc(rt_context* ctx, uint64_t bytes, void** d_ptr);
+int rt_device_free(rt_context* ctx, void* d_ptr);
+int rt_device_zero(rt_context* ctx, void* d_ptr, uint64_t bytes, void* stream);
+int rt_copy_to_host(rt_context* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+int rt_copy_to_device(rt_context* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+int rt_synchronize(rt_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCORE_H */

@@ -1,0 +1,276 @@
+// rt_host.cpp -- host halves of the path: BVH build, vertex transform, camera
+// frame, and the re-pack of upstream-layout arrays into the device layout.
+// Built with -ffp-contract=off: every expression is plain IEEE binary32 in the
+// operand order of the upstream code it replaces.
+#include "rt_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rtc {
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+inline V3 ld(const rt_float3& p) { return V3{p.x, p.y, p.z}; }
+inline float comp(const V3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+struct Box { V3 lo, hi; };
+
+inline void grow(Box& b, const V3& p) {
+    b.lo = V3{fminf(b.lo.x, p.x), fminf(b.lo.y, p.y), fminf(b.lo.z, p.z)};
+    b.hi = V3{fmaxf(b.hi.x, p.x), fmaxf(b.hi.y, p.y), fmaxf(b.hi.z, p.z)};
+}
+inline void grow(Box& b, const Box& o) {
+    b.lo = V3{fminf(b.lo.x, o.lo.x), fminf(b.lo.y, o.lo.y), fminf(b.lo.z, o.lo.z)};
+    b.hi = V3{fmaxf(b.hi.x, o.hi.x), fmaxf(b.hi.y, o.hi.y), fmaxf(b.hi.z, o.hi.z)};
+}
+inline Box box_of(const rt_triangle& t) {
+    Box b{ld(t.v[0].position), ld(t.v[0].position)};
+    grow(b, ld(t.v[1].position));
+    grow(b, ld(t.v[2].position));
+    return b;
+}
+inline Box node_box(const rt_bvh_node& n) { return Box{ld(n.box_min), ld(n.box_max)}; }
+inline void store_box(rt_bvh_node& n, const Box& b) {
+    n.box_min = rt_float3{b.lo.x, b.lo.y, b.lo.z};
+    n.box_max = rt_float3{b.hi.x, b.hi.y, b.hi.z};
+}
+
+// Median-split builder.  The permutation is carried by an index array; the
+// comparator reads the centroid table, so std::nth_element sees exactly the
+// comparison outcomes upstream's struct-array version sees (csrc/bvh.cpp:61-64)
+// and leaves the same arrangement behind -- which decides the leaf pairing.
+struct Builder {
+    const rt_triangle* tris;
+    std::vector<V3> centroid;
+    std::vector<int> order;
+    std::vector<rt_bvh_node>* out;
+
+    void emit_leaf(int first, int last) {
+        rt_bvh_node n;
+        std::memset(&n, 0, sizeof(n));
+        n.is_leaf = 1;
+        n.left = order[first];
+        n.right = -1;
+        Box b = box_of(tris[n.left]);
+        if (last > first) {
+            n.right = order[first + 1];
+            grow(b, box_of(tris[n.right]));
+        }
+        store_box(n, b);
+        out->push_back(n);
+    }
+
+    void split(int first, int last) {   // inclusive range, csrc/bvh.cpp:29-75
+        if (first + 1 >= last) { emit_leaf(first, last); return; }
+        Box cb{V3{INFINITY, INFINITY, INFINITY}, V3{-INFINITY, -INFINITY, -INFINITY}};
+        for (int i = first; i <= last; i++) grow(cb, centroid[order[i]]);
+        int axis = 0;
+        float widest = cb.hi.x - cb.lo.x;
+        float w = cb.hi.y - cb.lo.y;
+        if (w > widest) { axis = 1; widest = w; }
+        w = cb.hi.z - cb.lo.z;
+        if (w > widest) axis = 2;
+        const int mid = (first + last) / 2;
+        const V3* c = centroid.data();
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + last + 1,
+                         [c, axis](int a, int b) { return comp(c[a], axis) < comp(c[b], axis); });
+        split(first, mid);
+        const int left = (int)out->size() - 1;
+        split(mid + 1, last);
+        const int right = (int)out->size() - 1;
+        grow(cb, node_box((*out)[left]));
+        grow(cb, node_box((*out)[right]));
+        rt_bvh_node n;
+        std::memset(&n, 0, sizeof(n));
+        n.is_leaf = 0;
+        n.left = left;
+        n.right = right;
+        store_box(n, cb);
+        out->push_back(n);
+    }
+};
+
+}  // namespace
+
+int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out) {
+    out.clear();
+    out.reserve((size_t)n + 1);
+    Builder b;
+    b.tris = tris;
+    b.out = &out;
+    b.centroid.resize(n);
+    b.order.resize(n);
+    const float third = 1.f / 3.0f;   // upstream's float3 `/ 3.0f` multiplies by the reciprocal (common.cuh:148-153)
+    for (int i = 0; i < n; i++) {
+        const V3 a = ld(tris[i].v[0].position), bb = ld(tris[i].v[1].position), c = ld(tris[i].v[2].position);
+        b.centroid[i] = V3{((a.x + bb.x) + c.x) * third, ((a.y + bb.y) + c.y) * third, ((a.z + bb.z) + c.z) * third};
+        b.order[i] = i;
+    }
+    b.split(0, n - 1);
+    return (int)out.size();
+}
+
+void apply_transform(const rt_transform& xf, rt_triangle* tris, int n) {
+    // cuda/transforms.cu:47: degrees -> radians in double, then narrowed
+    const float rx = (float)(xf.rotation.x * M_PI / 180.0f);
+    const float ry = (float)(xf.rotation.y * M_PI / 180.0f);
+    const float rz = (float)(xf.rotation.z * M_PI / 180.0f);
+    const float cx = cosf(rx), sx = sinf(rx), cy = cosf(ry), sy = sinf(ry), cz = cosf(rz), sz = sinf(rz);
+    // cuda/transforms.cu:11-19
+    const float m[9] = {
+        cy * cz,                 -cy * sz,                 sy,
+        sx * sy * cz + cx * sz,  -sx * sy * sz + cx * cz,  -sx * cy,
+        -cx * sy * cz + sx * sz, cx * sy * sz + sx * cz,   cx * cy};
+    auto rot = [&m](rt_float3& v) {
+        const float x = v.x, y = v.y, z = v.z;
+        v.x = m[0] * x + m[1] * y + m[2] * z;
+        v.y = m[3] * x + m[4] * y + m[5] * z;
+        v.z = m[6] * x + m[7] * y + m[8] * z;
+    };
+    for (int t = 0; t < n; t++)
+        for (int k = 0; k < 3; k++) {
+            rt_vertex& v = tris[t].v[k];
+            v.position.x *= xf.scale.x; v.position.y *= xf.scale.y; v.position.z *= xf.scale.z;
+            rot(v.position);
+            v.position.x += xf.translation.x; v.position.y += xf.translation.y; v.position.z += xf.translation.z;
+            rot(v.normal);
+        }
+}
+
+CameraFrame camera_frame(int width, int height, const float pos[3], const float dir_in[3], const float up_in[3], float fov) {
+    // cuda/camera.cu:49-59
+    auto norm = [](V3 a) {
+        const float len = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+        return V3{a.x / len, a.y / len, a.z / len};
+    };
+    auto crs = [](V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+    V3 dir = norm(V3{dir_in[0], dir_in[1], dir_in[2]});
+    V3 up = norm(V3{up_in[0], up_in[1], up_in[2]});
+    const V3 right = crs(dir, up);
+    up = crs(right, dir);
+    const float aspect = (float)width / (float)height;
+    const float hh = tanf(fov / 2.0f);
+    const float hw = aspect * hh;
+    CameraFrame f;
+    f.pos[0] = pos[0]; f.pos[1] = pos[1]; f.pos[2] = pos[2];
+    // dir - hw*right - hh*up, where a - b is a + (-b)
+    f.lower_left[0] = (dir.x + (-(right.x * hw))) + (-(up.x * hh));
+    f.lower_left[1] = (dir.y + (-(right.y * hw))) + (-(up.y * hh));
+    f.lower_left[2] = (dir.z + (-(right.z * hw))) + (-(up.z * hh));
+    const float w2 = 2.0f * hw, h2 = 2.0f * hh;
+    f.dx[0] = right.x * w2; f.dx[1] = right.y * w2; f.dx[2] = right.z * w2;
+    f.dy[0] = up.x * h2; f.dy[1] = up.y * h2; f.dy[2] = up.z * h2;
+    f.width = width;
+    f.height = height;
+    return f;
+}
+
+// ---------------------------------------------------------------------------
+// Re-pack: upstream per-object arrays -> one global Node64 / TriIsect / TriShade set.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Packer {
+    PackedScene* ps;
+    const rt_object* obj;
+    int obj_index;
+    int max_depth;
+
+    static void put_box(ChildRec& c, const rt_bvh_node& n) {
+        c.bmin[0] = n.box_min.x; c.bmin[1] = n.box_min.y; c.bmin[2] = n.box_min.z;
+        c.bmax[0] = n.box_max.x; c.bmax[1] = n.box_max.y; c.bmax[2] = n.box_max.z;
+        c.aux = 0;
+    }
+
+    uint32_t add_triangle(int ti) {
+        const rt_triangle& t = obj->triangles[ti];
+        TriIsect r;
+        std::memset(&r, 0, sizeof(r));
+        const rt_float3 &a = t.v[0].position, &b = t.v[1].position, &c = t.v[2].position;
+        r.v0[0] = a.x; r.v0[1] = a.y; r.v0[2] = a.z;
+        r.e1[0] = b.x + (-a.x); r.e1[1] = b.y + (-a.y); r.e1[2] = b.z + (-a.z);
+        r.e2[0] = c.x + (-a.x); r.e2[1] = c.y + (-a.y); r.e2[2] = c.z + (-a.z);
+        TriShade s;
+        std::memset(&s, 0, sizeof(s));
+        for (int k = 0; k < 3; k++) {
+            float* n = k == 0 ? s.n0 : (k == 1 ? s.n1 : s.n2);
+            float* uv = k == 0 ? s.uv0 : (k == 1 ? s.uv1 : s.uv2);
+            n[0] = t.v[k].normal.x; n[1] = t.v[k].normal.y; n[2] = t.v[k].normal.z;
+            uv[0] = t.v[k].texcoord[0]; uv[1] = t.v[k].texcoord[1];
+        }
+        s.material_id = t.material_id;
+        const uint32_t p = (uint32_t)ps->isect.size();
+        ps->isect.push_back(r);
+        ps->shade.push_back(s);
+        ps->origin.push_back(TriOrigin{obj_index, ti});
+        return p;
+    }
+
+    // Returns the reference for upstream node `ni`, emitting packed records below it.
+    uint32_t emit(int ni, int depth) {
+        const rt_bvh_node& n = obj->bvh[ni];
+        if (n.is_leaf) {
+            uint32_t ref = REF_LEAF | add_triangle(n.left);
+            if (n.right >= 0) { add_triangle(n.right); ref |= REF_PAIR; }
+            return ref;
+        }
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+        const uint32_t me = (uint32_t)ps->nodes.size();
+        ps->nodes.emplace_back();
+        // children are emitted right-first so that memory order follows upstream's visiting order
+        const uint32_t rr = emit(n.right, depth + 1);
+        const uint32_t lr = emit(n.left, depth + 1);
+        Node64& out = ps->nodes[me];
+        put_box(out.c[0], obj->bvh[n.left]);
+        out.c[0].ref = lr;
+        put_box(out.c[1], obj->bvh[n.right]);
+        out.c[1].ref = rr;
+        return me;
+    }
+};
+
+}  // namespace
+
+int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
+    ps = PackedScene();
+    size_t total_tris = 0;
+    for (int i = 0; i < n_objects; i++) {
+        if (!objects[i].triangles || !objects[i].bvh || objects[i].n_triangles <= 0 || objects[i].n_bvh_nodes <= 0) {
+            err = "object " + std::to_string(i) + ": empty triangle or node array";
+            return -1;
+        }
+        total_tris += (size_t)objects[i].n_triangles;
+    }
+    if (total_tris > (size_t)REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
+    ps.isect.reserve(total_tris);
+    ps.shade.reserve(total_tris);
+    ps.origin.reserve(total_tris);
+    ps.top.resize(n_objects);
+    for (int i = 0; i < n_objects; i++) {
+        const rt_object& o = objects[i];
+        // validate child indices before walking (a bad index would otherwise read out of bounds)
+        for (int k = 0; k < o.n_bvh_nodes; k++) {
+            const rt_bvh_node& n = o.bvh[k];
+            const int lim = n.is_leaf ? o.n_triangles : o.n_bvh_nodes;
+            if (n.left < 0 || n.left >= lim || n.right >= lim || (!n.is_leaf && (n.right < 0 || n.left >= k || n.right >= k))) {
+                err = "object " + std::to_string(i) + ": node " + std::to_string(k) + " has an invalid child index";
+                return -1;
+            }
+        }
+        Packer p{&ps, &o, i, 0};
+        const int root = o.n_bvh_nodes - 1;   // cuda/raytrace.cu:49
+        const size_t tris_before = ps.isect.size();
+        const uint32_t ref = p.emit(root, 0);
+        Packer::put_box(ps.top[i], o.bvh[root]);
+        ps.top[i].ref = ref;
+        if (p.max_depth > ps.max_depth) ps.max_depth = p.max_depth;
+        (void)tris_before;
+    }
+    return 0;
+}
+
+}  // namespace rtc

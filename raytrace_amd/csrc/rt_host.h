@@ -1,0 +1,36 @@
+// rt_host.h -- host-side helpers behind the C ABI (no HIP types here).
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtcore.h"
+#include "rt_packed.h"
+
+namespace rtc {
+
+struct CameraFrame {          // what cuda/camera.cu:49-59 passes to its kernel
+    float pos[3];
+    float lower_left[3];
+    float dx[3];
+    float dy[3];
+    int width, height;
+};
+
+struct PackedScene {
+    std::vector<ChildRec> top;       // one per upstream object, in object order
+    std::vector<Node64> nodes;
+    std::vector<TriIsect> isect;
+    std::vector<TriShade> shade;
+    std::vector<TriOrigin> origin;
+    int max_depth = 0;               // deepest chain of inner nodes below any object root
+};
+
+int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out);
+void apply_transform(const rt_transform& xf, rt_triangle* tris, int n);
+CameraFrame camera_frame(int width, int height, const float pos[3], const float dir[3], const float up[3], float fov);
+int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err);
+
+}  // namespace rtc
+#endif

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One rt_context on cuda:0 for the whole GPU session (fails loudly when the extension or GPU is missing)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from raytrace_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()

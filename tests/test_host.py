@@ -1,0 +1,109 @@
+"""CPU tests of the product's host halves (librtcore.so without touching a GPU) against the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from raytrace_amd import capi, procgen, scene
+from tests.util import same_nodes, same_triangles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = capi.load()
+    header = open(os.path.join(ROOT, "include", "rtcore.h")).read()
+    declared = sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in rtcore.h but not exported"
+    assert sorted(capi.EXPORTS) == declared
+    assert lib.rt_abi_version() == 1
+
+
+def test_pod_layouts_match_upstream_sizes():
+    assert capi.TRIANGLE_DTYPE.itemsize == 104 and capi.NODE_DTYPE.itemsize == 36 and capi.MATERIAL_DTYPE.itemsize == 32
+    assert capi.TRIANGLE_DTYPE == orc.TRIANGLE_DTYPE and capi.NODE_DTYPE == orc.NODE_DTYPE
+
+
+def _random_tris(n, seed, spread=10.0, size=1.0):
+    rng = np.random.RandomState(seed)
+    tris = np.zeros(n, dtype=capi.TRIANGLE_DTYPE)
+    c = rng.uniform(-spread, spread, size=(n, 1, 3))
+    tris["v"]["position"] = (c + rng.uniform(-size, size, size=(n, 3, 3))).astype(np.float32)
+    tris["v"]["normal"] = rng.uniform(-1, 1, size=(n, 3, 3)).astype(np.float32)
+    return tris
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 33, 1000, 20011])
+def test_build_bvh_is_node_for_node_identical(n):
+    tris = _random_tris(n, n)
+    assert same_nodes(capi.build_bvh(tris), orc.build_bvh(tris))
+
+
+def test_build_bvh_with_equal_centroids_and_degenerate_triangles():
+    # ties in the split key exercise the exact permutation nth_element leaves behind
+    tris = _random_tris(257, 5)
+    tris["v"]["position"][:, :, 0] = np.float32(1.0)            # flat in x: longest axis is y or z
+    tris["v"]["position"][::3] = tris["v"]["position"][0]        # many identical triangles
+    tris["v"]["position"][5] = 0.0                               # a zero-area triangle
+    assert same_nodes(capi.build_bvh(tris), orc.build_bvh(tris))
+    grid = _random_tris(512, 6)
+    grid["v"]["position"] = np.round(grid["v"]["position"])      # integer lattice: many equal keys
+    assert same_nodes(capi.build_bvh(grid), orc.build_bvh(grid))
+
+
+def test_build_bvh_rejects_bad_arguments():
+    lib = capi.load()
+    nodes = np.zeros(4, dtype=capi.NODE_DTYPE)
+    tris = _random_tris(8, 1)
+    assert lib.rt_build_bvh(tris.ctypes.data, 0, nodes.ctypes.data, 4) == -1
+    assert lib.rt_build_bvh(None, 8, nodes.ctypes.data, 4) == -1
+    assert lib.rt_build_bvh(tris.ctypes.data, 8, nodes.ctypes.data, 4) == -5      # capacity
+    assert b"need" in lib.rt_last_error()
+
+
+@pytest.mark.parametrize("xf", [((1, 1, 1), (0, 0, 0), (0, 0, 0)), ((1e3, 1e3, 1e3), (0, 0, 0), (90, 0, 0)),
+                                ((40, 0, 80), (240, 40, 100), (90, 0, -80)), ((1, 1, 1), (0, 0, 0), (90, 100, 0)),
+                                ((0.5, 2, 3), (-1.25, 7, 1e-3), (-20, 33.3, 361))])
+def test_apply_transform_is_bit_identical(xf):
+    a = _random_tris(500, 9)
+    b = a.copy()
+    b["v"] = a["v"]
+    capi.apply_transform(a, *xf)
+    orc.apply_transform(b, *xf)
+    assert same_triangles(a, b)
+
+
+def test_scene_arrays_identical_through_both_backends():
+    asm = scene.material_box()
+    for (t1, n1), (t2, n2) in zip(scene.finalize(asm), scene.finalize(asm, orc.OracleBackend())):
+        assert same_triangles(t1, t2) and same_nodes(n1, n2)
+
+
+def test_material_assembly_follows_loader_rules():
+    asm = scene.formula1(width=8, height=8, n_samples=1, detail=0.01, tex_size=8)
+    m = asm.materials
+    # base material first, then one per MTL record; planes add one base material each
+    assert len(m) == 1 + 10 + 4
+    assert m[0]["type"] == capi.MAT_REFRACTIVE and m[0]["optical_density"] == 3.0
+    assert m[1]["type"] == capi.MAT_METAL and m[1]["texture"] == 0                    # illum 2 with map_Kd
+    assert m[5]["type"] == capi.MAT_REFRACTIVE and m[5]["optical_density"] == 1.5      # illum 4 takes Ni ...
+    np.testing.assert_allclose(m[5]["albedo"], [0.75 + 0.25 * 0.9, 0.75 + 0.25 * 0.95, 1.0], rtol=1e-6)   # ... and blends Kd with d
+    assert m[6]["optical_density"] == 1.5                                              # ... which persists for later records
+    assert m[9]["type"] == capi.MAT_LIGHT and tuple(m[9]["albedo"]) == (1.0, np.float32(0.15), np.float32(0.1))
+    assert all(t["material_id"].min() >= 0 and t["material_id"].max() < len(m) for t in asm.triangles)
+    glass = scene.formula1(width=8, height=8, n_samples=1, detail=0.01, glass=True)
+    assert len(glass.materials) == 1 + 4 and all((t["material_id"] == 0).all() for t in glass.triangles[:-4])
+
+
+def test_context_calls_fail_cleanly_without_arguments():
+    lib = capi.load()
+    assert lib.rt_create(0, None) == -1
+    assert lib.rt_set_option(None, 1, 1) == -1
+    assert lib.rt_upload_scene(None, None, 0, None, 0, None, 0) == -1
+    assert lib.rt_raytrace(None, 0, 0, 0, 1, 0, None, 0.0, None, None) == -1
+    assert lib.rt_last_error() != b""
