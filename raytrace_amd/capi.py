@@ -65,6 +65,14 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} is not built: run `make` (or __graft_entry__.build()) first")
+    # PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  A process that will also use torch
+    # (for device memory, streams, RCCL) must bind ONE HIP runtime: import torch first so that librtcore's
+    # NEEDED libamdhip64.so.7 resolves to the copy torch already loaded.  Loading in the other order leaves the
+    # process with a runtime that reports no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
     fp = C.POINTER(C.c_float)
