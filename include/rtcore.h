@@ -108,7 +108,10 @@ enum {
 /* options for rt_set_option */
 enum {
     RT_OPT_COUNTERS = 1,      /* 0 = rays/paths only (default), 1 = also box/triangle/shade/texture counts */
-    RT_OPT_XCD_REMAP = 2      /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
+    RT_OPT_XCD_REMAP = 2,     /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
+    RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 16); scheduling only, results unchanged */
+    RT_OPT_PASS = 4           /* samples per pixel buffered between path and accumulate kernels (default 64);
+                                 scheduling only; the context holds pass * n_pixel * 12 bytes */
 };
 
 const char* rt_last_error(void);

@@ -33,7 +33,7 @@ MAT_NONE, MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_REFRACTIVE, MAT_REFLECTIVE =
 
 CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS = range(6)
 CNT_COUNT = 8
-OPT_COUNTERS, OPT_XCD_REMAP = 1, 2
+OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS = 1, 2, 3, 4
 
 
 class RtObject(C.Structure):

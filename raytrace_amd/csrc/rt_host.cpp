@@ -235,6 +235,27 @@ struct Packer {
 
 }  // namespace
 
+static ChildRec build_top(PackedScene& ps, int first, int last, int depth, int& max_depth) {
+    if (last - first == 1) return ps.top[first];
+    if (depth + 1 > max_depth) max_depth = depth + 1;
+    const int mid = (first + last) / 2;
+    const uint32_t me = (uint32_t)ps.nodes.size();
+    ps.nodes.emplace_back();
+    const ChildRec lower = build_top(ps, first, mid, depth + 1, max_depth);
+    const ChildRec upper = build_top(ps, mid, last, depth + 1, max_depth);
+    Node64& n = ps.nodes[me];
+    n.c[1] = lower;     // right child: visited first
+    n.c[0] = upper;
+    ChildRec r;
+    for (int a = 0; a < 3; a++) {
+        r.bmin[a] = lower.bmin[a] < upper.bmin[a] ? lower.bmin[a] : upper.bmin[a];
+        r.bmax[a] = lower.bmax[a] > upper.bmax[a] ? lower.bmax[a] : upper.bmax[a];
+    }
+    r.ref = me;
+    r.aux = 0;
+    return r;
+}
+
 int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
     ps = PackedScene();
     size_t total_tris = 0;
@@ -270,6 +291,16 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
         if (p.max_depth > ps.max_depth) ps.max_depth = p.max_depth;
         (void)tris_before;
     }
+    // Object-level tree.  Upstream loops over the objects in ascending order and starts each
+    // with a slab test of its root box (cuda/raytrace.cu:217-219, 49-55).  The same visiting order
+    // falls out of the ordinary right-child-first walk when the objects are hung under a balanced
+    // tree over the INDEX sequence whose right child holds the lower half: whole runs of
+    // objects are skipped by one test, and every object still gets the test of its own root box.
+    // A run's box is the union of its members' boxes, so it is hit whenever a member is and
+    // its t_near never exceeds a member's (the slab arithmetic is monotone in the bounds).
+    int top_depth = 0;
+    ps.root = build_top(ps, 0, n_objects, 0, top_depth);
+    ps.max_depth += top_depth;
     return 0;
 }
 

@@ -20,11 +20,12 @@ struct CameraFrame {          // what cuda/camera.cu:49-59 passes to its kernel
 
 struct PackedScene {
     std::vector<ChildRec> top;       // one per upstream object, in object order
+    ChildRec root;                   // the whole scene: root of the object-level tree
     std::vector<Node64> nodes;
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
     std::vector<TriOrigin> origin;
-    int max_depth = 0;               // deepest chain of inner nodes below any object root
+    int max_depth = 0;               // deepest chain of inner nodes below the scene root (= stack slots needed)
 };
 
 int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out);

@@ -35,7 +35,7 @@ using namespace rtc;
 // device-side scene view and parameters
 // ---------------------------------------------------------------------------
 struct SceneDev {
-    const ChildRec* top;
+    ChildRec root;            // box + reference of the whole scene (root of the object-level tree)
     const Node64* nodes;
     const TriIsect* isect;
     const TriShade* shade;
@@ -43,19 +43,19 @@ struct SceneDev {
     const MatDev* mats;
     const TexDev* tex;
     const uint32_t* texels;
-    int n_objects;
     int n_materials;
 };
 
 struct PathParams {
     CameraFrame cam;
     int n_pixel;
-    int first_sample, n_samples, batch;
+    int first_sample, n_samples, batch;   // this pass: global samples [first_sample, first_sample + n_samples)
+    int chunk, n_chunks;                  // samples per lane; lanes (chunks) per pixel in this pass
     int max_depth;
     float ambient[3];
     float rr;
     uint32_t key0, key1;
-    float* out;
+    float* slots;                         // [n_samples][n_pixel][3]: radiance of each path of the pass
     unsigned long long* counters;
     int tiles_x, tiles_y;
     int xcd_remap;
@@ -185,43 +185,34 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
     if (!rej) { h.t = t; h.u = u; h.v = v; h.tri = p; }
 }
 
-// Closest hit over the whole scene in upstream's visiting order (cuda/raytrace.cu:44-78, 214-219).
+// Closest hit over the whole scene in upstream's visiting order (cuda/raytrace.cu:44-78, 214-219):
+// right child first, leaf left triangle then right, prune on t_near > best t when a node comes off the
+// stack.  The objects hang under the object-level tree, so there is one walk, not one per object.
 // `stack` points at this lane's column of the LDS stack; consecutive slots are `stride` entries apart.
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, uint2* stack, int stride,
                                             uint32_t& n_box, uint32_t& n_tri) {
     h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-    int obj = 0;
     int sp = 0;
     uint32_t cur = REF_NONE;
-    for (;;) {
-        if (cur == REF_NONE) {
-            if (sp > 0) {
-                // a deferred left sibling: the slab test was done when it was pushed, the
-                // t_near > best-t prune happens now, as upstream does at pop time (raytrace.cu:55)
-                --sp;
-                const uint2 e = stack[sp * stride];
-                if (__uint_as_float(e.y) > h.t) continue;
-                cur = e.x;
-            } else {
-                if (obj >= sc.n_objects) break;
-                const float4* q = reinterpret_cast<const float4*>(sc.top + obj);
-                const float4 a = q[0], b = q[1];
-                obj++;
-                float tn;
-                if (COUNT) n_box++;
-                if (!slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tn)) continue;
-                if (tn > h.t) continue;
-                cur = __float_as_uint(b.z);
-            }
+    {
+        float tn;
+        if (COUNT) n_box++;
+        if (slab(sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0], sc.root.bmax[1], sc.root.bmax[2], r, tn))
+            cur = sc.root.ref;
+    }
+    // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            --sp;
+            const uint2 e = stack[sp * stride];
+            if (!(__uint_as_float(e.y) > h.t)) return e.x;
         }
-        if (cur & REF_LEAF) {
-            const uint32_t p = cur & REF_MASK;
-            if (COUNT) n_tri += (cur & REF_PAIR) ? 2u : 1u;
-            tri_test(sc.isect, p, r, h);
-            if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
-            cur = REF_NONE;
-        } else {
+        return REF_NONE;
+    };
+    for (;;) {
+        // inner nodes: one 64-byte record decides both children.  REF_NONE has the leaf bit set and ends the loop.
+        while (!(cur & REF_LEAF)) {
             const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 a = q[0], b = q[1], c = q[2], d = q[3];
             float tnl, tnr;
@@ -229,15 +220,23 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, H
             const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
             const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
             const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
-            // upstream pushes left then right, so the right child is visited first.  A left child
-            // whose t_near already exceeds the best t can be dropped now: best t only shrinks.
+            // upstream pushes left then right, so the right child is visited first.  A left child whose
+            // t_near already exceeds the best t can be dropped now: the best t only shrinks.
             if (hr) {
                 if (hl) { stack[sp * stride] = make_uint2(refl, __float_as_uint(tnl)); sp++; }
                 cur = refr;
+            } else if (hl) {
+                cur = refl;
             } else {
-                cur = hl ? refl : REF_NONE;
+                cur = pop();
             }
         }
+        if (cur == REF_NONE) break;
+        const uint32_t p = cur & REF_MASK;
+        if (COUNT) n_tri += (cur & REF_PAIR) ? 2u : 1u;
+        tri_test(sc.isect, p, r, h);
+        if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
+        cur = pop();
     }
 }
 
@@ -304,20 +303,8 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------
-// pixel <-> lane mapping
+// camera
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void tile_of_block(int bid, int nblocks, int tiles_x, int xcd_remap, int& tx, int& ty) {
-    int id = bid;
-    if (xcd_remap) {
-        // workgroups b and b+8 share an XCD: hand each of the 8 residue classes a
-        // contiguous run of tiles (bijective for any nblocks)
-        const int q = nblocks >> 3, rem = nblocks & 7, x = bid & 7;
-        id = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (bid >> 3);
-    }
-    tx = id % tiles_x;
-    ty = id / tiles_x;
-}
-
 __device__ __forceinline__ v3 primary_dir(const CameraFrame& cam, int x, int y, float ju, float jv) {   // camera.cu:35-39
     const float u = ((float)x + ju) / (float)cam.width;
     const float v = ((float)y + jv) / (float)cam.height;
@@ -330,13 +317,24 @@ __device__ __forceinline__ v3 primary_dir(const CameraFrame& cam, int x, int y, 
 // ---------------------------------------------------------------------------
 // the path kernel
 // ---------------------------------------------------------------------------
+// One lane traces `chunk` consecutive samples of one pixel as a flat state machine and writes each
+// finished path's radiance into that sample's slot; accumulate_kernel then sums the slots per pixel
+// in upstream's order.  Work unit = (16x16 pixel tile, chunk of samples): many short workgroups,
+// so neither a costly pixel nor a costly tile can leave the chip idle at the end of a launch.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams pp) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     uint2* stack = lds_stack + threadIdx.x;
 
-    int tx, ty;
-    tile_of_block(blockIdx.x, gridDim.x, pp.tiles_x, pp.xcd_remap, tx, ty);
+    int id = blockIdx.x;
+    if (pp.xcd_remap) {
+        // workgroups b and b+8 share an XCD: hand each of the 8 residue classes a contiguous run of
+        // work units, i.e. one band of the image (bijective for any grid size)
+        const int nb = gridDim.x, q = nb >> 3, rem = nb & 7, xc = id & 7;
+        id = (xc < rem ? xc * (q + 1) : rem * (q + 1) + (xc - rem) * q) + (id >> 3);
+    }
+    const int tile = id / pp.n_chunks, chunk_id = id - tile * pp.n_chunks;
+    const int tx = tile % pp.tiles_x, ty = tile / pp.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -348,17 +346,13 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
 
     uint32_t n_rays = 0, n_box = 0, n_tri = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
 
-    v3 out = mk3(0.0f, 0.0f, 0.0f);
-    if (inside) out = mk3(pp.out[3 * (size_t)pixel], pp.out[3 * (size_t)pixel + 1], pp.out[3 * (size_t)pixel + 2]);
-
-    int sample = pp.first_sample;
-    const int end = pp.first_sample + pp.n_samples;
+    const int pass_end = pp.first_sample + pp.n_samples;
+    int sample = pp.first_sample + chunk_id * pp.chunk;
+    const int end = min(sample + pp.chunk, pass_end);
     bool alive = inside && (sample < end);
 
-    // per-batch and per-path state
-    int batch_end = 0;
+    int jitter_batch = -1;
     v3 prim_dir = mk3(0.0f, 0.0f, 1.0f);
-    v3 total = mk3(0.0f, 0.0f, 0.0f);
     v3 color = mk3(1.0f, 1.0f, 1.0f);
     int depth = 0;
     Rng rng;
@@ -366,25 +360,24 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     RayD ray;
     ray_set(ray, cam_pos, prim_dir);
 
-    auto begin_batch = [&]() {
-        const uint32_t bi = (uint32_t)(sample / pp.batch);
-        const int be = (int)(bi + 1) * pp.batch;
-        batch_end = be < end ? be : end;
-        Rng j;
-        rng_init(j, (uint32_t)pixel, bi, 1u);
-        const float ju = rng_uniform(j, k0, k1);
-        const float jv = rng_uniform(j, k0, k1);
-        prim_dir = primary_dir(pp.cam, x, y, ju, jv);
-        total = mk3(0.0f, 0.0f, 0.0f);
-    };
     auto begin_path = [&]() {
+        const int bi = sample / pp.batch;
+        if (bi != jitter_batch) {
+            // one jittered primary ray per pixel per semantic batch (camera.cu:35-40, worker.cpp:71-78)
+            jitter_batch = bi;
+            Rng j;
+            rng_init(j, (uint32_t)pixel, (uint32_t)bi, 1u);
+            const float ju = rng_uniform(j, k0, k1);
+            const float jv = rng_uniform(j, k0, k1);
+            prim_dir = primary_dir(pp.cam, x, y, ju, jv);
+        }
         ray_set(ray, cam_pos, prim_dir);                 // raytrace.cu:210
         color = mk3(1.0f, 1.0f, 1.0f);                   // :211
         depth = pp.max_depth;                            // :212
         rng_init(rng, (uint32_t)pixel, (uint32_t)sample, 0u);
     };
 
-    if (alive) { begin_batch(); begin_path(); }
+    if (alive) begin_path();
 
     while (alive) {
         bool finished = false, contributes = true;
@@ -491,22 +484,17 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
         }
         if (finished) {
             n_paths++;
-            if (contributes) total = vadd(total, color);                            // raytrace.cu:244
+            // a path that ran out of depth adds nothing (raytrace.cu:243): its slot holds +0, which is neutral
+            // in the ordered sum because every other term is a product of non-negative factors
+            if (!contributes) color = mk3(0.0f, 0.0f, 0.0f);
+            float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+            slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
             sample++;
-            if (sample == batch_end) {
-                out = vadd(out, total);                                             // raytrace.cu:246
-                if (sample >= end) alive = false;
-                else begin_batch();
-            }
-            if (alive) begin_path();
+            if (sample >= end) alive = false;
+            else begin_path();
         }
     }
 
-    if (inside) {
-        pp.out[3 * (size_t)pixel] = out.x;
-        pp.out[3 * (size_t)pixel + 1] = out.y;
-        pp.out[3 * (size_t)pixel + 2] = out.z;
-    }
     wave_add(pp.counters + RT_CNT_RAYS, n_rays);
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
     if (COUNT) {
@@ -515,6 +503,35 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
         wave_add(pp.counters + RT_CNT_TEX_FETCHES, n_tex);
     }
+}
+
+// Per pixel: sum the pass's slots in sample order into the running batch total and add every completed
+// batch total to the output buffer -- the order of cuda/raytrace.cu:208-246 with the batch loop of
+// csrc/worker.cpp:71-91 around it.  A batch that straddles two passes of one call carries its running
+// total in `carry`; the last pass of a call flushes a final partial batch (the frame's remainder batch).
+__global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int first_sample, int n_samples, int batch, int flush,
+                                                              const float* __restrict__ slots, float* __restrict__ carry,
+                                                              float* __restrict__ out) {
+    const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n_pixel) return;
+    float ox = out[3 * (size_t)i], oy = out[3 * (size_t)i + 1], oz = out[3 * (size_t)i + 2];
+    float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+    int in_batch = first_sample % batch;            // samples of the current batch summed by earlier passes
+    if (in_batch) { tx = carry[3 * (size_t)i]; ty = carry[3 * (size_t)i + 1]; tz = carry[3 * (size_t)i + 2]; }
+    for (int s = 0; s < n_samples; s++) {
+        const float* p = slots + ((size_t)s * (size_t)n_pixel + (size_t)i) * 3;
+        tx += p[0]; ty += p[1]; tz += p[2];
+        if (++in_batch == batch) {
+            ox += tx; oy += ty; oz += tz;
+            tx = ty = tz = 0.0f;
+            in_batch = 0;
+        }
+    }
+    if (in_batch) {
+        if (flush) { ox += tx; oy += ty; oz += tz; }
+        else { carry[3 * (size_t)i] = tx; carry[3 * (size_t)i + 1] = ty; carry[3 * (size_t)i + 2] = tz; }
+    }
+    out[3 * (size_t)i] = ox; out[3 * (size_t)i + 1] = oy; out[3 * (size_t)i + 2] = oz;
 }
 
 // ---------------------------------------------------------------------------
@@ -590,7 +607,7 @@ static int fail(int code, const std::string& msg) { g_last_error = msg; return c
 struct rt_context {
     int device = 0;
     SceneDev dev{};
-    void* d_top = nullptr; void* d_nodes = nullptr; void* d_isect = nullptr; void* d_shade = nullptr;
+    void* d_nodes = nullptr; void* d_isect = nullptr; void* d_shade = nullptr;
     void* d_origin = nullptr; void* d_mats = nullptr; void* d_tex = nullptr; void* d_texels = nullptr;
     unsigned long long* d_counters = nullptr;
     bool have_scene = false, have_camera = false;
@@ -598,12 +615,16 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
+    int opt_chunk = 16;              // samples one lane traces in a row
+    int opt_pass = 64;               // samples per pixel held in the slot buffer at once
+    float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
+    size_t slots_bytes = 0;
     int stack_slots = 1;
     uint64_t stats[8] = {0};
 };
 
 static void free_scene(rt_context* c) {
-    void** ptrs[] = {&c->d_top, &c->d_nodes, &c->d_isect, &c->d_shade, &c->d_origin, &c->d_mats, &c->d_tex, &c->d_texels};
+    void** ptrs[] = {&c->d_nodes, &c->d_isect, &c->d_shade, &c->d_origin, &c->d_mats, &c->d_tex, &c->d_texels};
     for (void** p : ptrs) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
     c->have_scene = false;
 }
@@ -658,6 +679,7 @@ int rt_destroy(rt_context* ctx) {
     (void)hipDeviceSynchronize();
     free_scene(ctx);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     delete ctx;
     return RT_OK;
 }
@@ -667,6 +689,12 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     switch (option) {
     case RT_OPT_COUNTERS: ctx->opt_counters = value ? 1 : 0; return RT_OK;
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
+    case RT_OPT_CHUNK:
+        if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "rt_set_option: chunk must be 1..65536");
+        ctx->opt_chunk = value; return RT_OK;
+    case RT_OPT_PASS:
+        if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "rt_set_option: pass must be 1..65536");
+        ctx->opt_pass = value; return RT_OK;
     default: return fail(RT_ERR_INVALID, "rt_set_option: unknown option");
     }
 }
@@ -717,7 +745,6 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     free_scene(ctx);
     uint64_t bytes = 0;
     int rc;
-    if ((rc = upload_vec(ps.top, &ctx->d_top, bytes))) return rc;
     if ((rc = upload_vec(ps.nodes, &ctx->d_nodes, bytes))) return rc;
     if ((rc = upload_vec(ps.isect, &ctx->d_isect, bytes))) return rc;
     if ((rc = upload_vec(ps.shade, &ctx->d_shade, bytes))) return rc;
@@ -725,7 +752,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     if ((rc = upload_vec(mats, &ctx->d_mats, bytes))) return rc;
     if ((rc = upload_vec(tex, &ctx->d_tex, bytes))) return rc;
     if ((rc = upload_vec(texels, &ctx->d_texels, bytes))) return rc;
-    ctx->dev.top = (const ChildRec*)ctx->d_top;
+    ctx->dev.root = ps.root;
     ctx->dev.nodes = (const Node64*)ctx->d_nodes;
     ctx->dev.isect = (const TriIsect*)ctx->d_isect;
     ctx->dev.shade = (const TriShade*)ctx->d_shade;
@@ -733,7 +760,6 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->dev.mats = (const MatDev*)ctx->d_mats;
     ctx->dev.tex = (const TexDev*)ctx->d_tex;
     ctx->dev.texels = (const uint32_t*)ctx->d_texels;
-    ctx->dev.n_objects = n_objects;
     ctx->dev.n_materials = n_materials;
     ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
     ctx->stats[0] = ps.isect.size();
@@ -779,26 +805,47 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     if (spp == 0) return RT_OK;
     if (stack_bytes(ctx) > 64 * 1024) return fail(RT_ERR_INVALID, "rt_raytrace: BVH deeper than the LDS stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    // slot buffer: one float3 per (sample of the pass, pixel); grown on demand, kept by the context
+    const int pass = spp < ctx->opt_pass ? spp : ctx->opt_pass;
+    const size_t plane = (size_t)n_pixel * 3 * sizeof(float);
+    const size_t need = ((size_t)pass + 1) * plane;
+    if (need > ctx->slots_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ctx->d_slots) { HIP_TRY(hipFree(ctx->d_slots)); ctx->d_slots = nullptr; ctx->slots_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&ctx->d_slots, need));
+        ctx->slots_bytes = need;
+    }
     PathParams pp;
     pp.cam = ctx->cam;
     pp.n_pixel = n_pixel;
-    pp.first_sample = first_sample; pp.n_samples = spp; pp.batch = semantic_batch;
+    pp.batch = semantic_batch;
     pp.max_depth = max_depth;
     pp.ambient[0] = ambient[0]; pp.ambient[1] = ambient[1]; pp.ambient[2] = ambient[2];
     pp.rr = russian_roulette;
     pp.key0 = (uint32_t)ctx->seed; pp.key1 = (uint32_t)(ctx->seed >> 32);
-    pp.out = d_output;
+    pp.slots = ctx->d_slots;
     pp.counters = ctx->d_counters;
     pp.tiles_x = (ctx->cam.width + 15) / 16;
     pp.tiles_y = (ctx->cam.height + 15) / 16;
     pp.xcd_remap = ctx->opt_xcd;
-    const int nblocks = pp.tiles_x * pp.tiles_y;
-    hipStream_t s = (hipStream_t)stream;
-    if (ctx->opt_counters)
-        hipLaunchKernelGGL(path_kernel<true>, dim3(nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
-    else
-        hipLaunchKernelGGL(path_kernel<false>, dim3(nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
-    HIP_TRY(hipGetLastError());
+    pp.chunk = ctx->opt_chunk;
+    for (int done = 0; done < spp; done += pass) {
+        pp.first_sample = first_sample + done;
+        pp.n_samples = spp - done < pass ? spp - done : pass;
+        pp.n_chunks = (pp.n_samples + pp.chunk - 1) / pp.chunk;
+        const long long nblocks = (long long)pp.tiles_x * pp.tiles_y * pp.n_chunks;
+        if (nblocks > 0x7FFFFFFFLL) return fail(RT_ERR_INVALID, "rt_raytrace: grid too large");
+        if (ctx->opt_counters)
+            hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+        else
+            hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixel + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, n_pixel, pp.first_sample,
+                           pp.n_samples, semantic_batch, done + pass >= spp ? 1 : 0, (const float*)ctx->d_slots,
+                           ctx->d_slots + (size_t)pass * (size_t)n_pixel * 3, d_output);
+        HIP_TRY(hipGetLastError());
+    }
     return RT_OK;
 }
 
