@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the bounded CPU-baseline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-image", default="")
+    ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = library default)")
+    ap.add_argument("--pass-spp", type=int, default=0, help="samples per buffered pass (0 = library default)")
+    ap.add_argument("--lds-slots", type=int, default=0, help="traversal stack levels in LDS (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -88,6 +91,12 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.upload_scene(objs, asm.materials, asm.textures)
     stats = ctx.scene_stats()
+    if args.chunk:
+        ctx.set_option(capi.OPT_CHUNK, args.chunk)
+    if args.pass_spp:
+        ctx.set_option(capi.OPT_PASS, args.pass_spp)
+    if args.lds_slots:
+        ctx.set_option(capi.OPT_LDS_SLOTS, args.lds_slots)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height
@@ -128,7 +137,8 @@ def main():
     rays_i = max(1, c[capi.CNT_RAYS])
     mix = {"box_tests_per_ray": c[capi.CNT_BOX_TESTS] / rays_i, "tri_tests_per_ray": c[capi.CNT_TRI_TESTS] / rays_i,
            "shaded_per_ray": c[capi.CNT_SHADED] / rays_i, "tex_per_ray": c[capi.CNT_TEX_FETCHES] / rays_i,
-           "rays_per_path": c[capi.CNT_RAYS] / max(1, c[capi.CNT_PATHS])}
+           "rays_per_path": c[capi.CNT_RAYS] / max(1, c[capi.CNT_PATHS]), "max_stack": c[capi.CNT_MAX_STACK],
+           "stack_slots_needed": stats["stack_slots"]}
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
     ctx.set_option(capi.OPT_COUNTERS, 0)
 

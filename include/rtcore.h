@@ -102,6 +102,7 @@ enum {
     RT_CNT_SHADED,            /* hits that reached triangle_interpolate */
     RT_CNT_TEX_FETCHES,       /* bilinear texture fetches */
     RT_CNT_PATHS,             /* camera samples finished */
+    RT_CNT_MAX_STACK,         /* deepest traversal stack seen (only with RT_OPT_COUNTERS) */
     RT_CNT_COUNT = 8
 };
 
@@ -109,9 +110,10 @@ enum {
 enum {
     RT_OPT_COUNTERS = 1,      /* 0 = rays/paths only (default), 1 = also box/triangle/shade/texture counts */
     RT_OPT_XCD_REMAP = 2,     /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
-    RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 16); scheduling only, results unchanged */
-    RT_OPT_PASS = 4           /* samples per pixel buffered between path and accumulate kernels (default 64);
-                                 scheduling only; the context holds pass * n_pixel * 12 bytes */
+    RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
+    RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 256);
+                                 scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
+    RT_OPT_LDS_SLOTS = 5      /* traversal-stack levels kept in LDS (default 12); deeper levels spill to private memory */
 };
 
 const char* rt_last_error(void);

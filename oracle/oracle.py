@@ -46,7 +46,7 @@ def load():
     lib.orc_apply_transform.restype = None
     lib.orc_philox4x32_10.argtypes = [vp, vp, vp]
     lib.orc_philox4x32_10.restype = None
-    lib.orc_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]
+    lib.orc_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     lib.orc_uniforms.restype = None
     lib.orc_scene_create.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     lib.orc_scene_create.restype = vp
@@ -66,7 +66,7 @@ def load():
     lib.orc_post_process.restype = None
     lib.orc_tex2d.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.orc_tex2d.restype = None
-    lib.orc_scatter.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
+    lib.orc_scatter.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
     lib.orc_num_threads.restype = C.c_int
     assert lib.orc_sizeof(0) == 104 and lib.orc_sizeof(1) == 36 and lib.orc_sizeof(2) == 32 and lib.orc_sizeof(3) == 24
     assert lib.orc_sizeof(4) == C.sizeof(RenderParams)
@@ -110,9 +110,10 @@ def philox(ctr, key):
     return out
 
 
-def uniforms(seed, pixel, index, stream, n):
-    out = np.zeros(n, dtype=np.float32)
-    load().orc_uniforms(seed, pixel, index, stream, n, out.ctypes.data)
+def uniforms(seed, pixel, index, slot, stream):
+    """The four (0,1] draws at one counter address."""
+    out = np.zeros(4, dtype=np.float32)
+    load().orc_uniforms(seed, pixel, index, slot, stream, out.ctypes.data)
     return out
 
 

@@ -239,27 +239,28 @@ static inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], u
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// One independent stream per (pixel, index, stream id): counter word 2 counts
-// 4-draw blocks.  stream 0 = the path's scatter/roulette draws for sample
-// `index`; stream 1 = the primary-ray jitter of semantic batch `index`.
+// Draw addressing.  Every random number a path uses has a fixed address, so a path can be evaluated by
+// any lane of any launch in any order:
+//   counter = (pixel, index, slot, stream), key = (seed low word, seed high word)
+//   stream 1, index = semantic batch, slot 0: words 0,1 = the primary-ray jitter (u, v) of that batch
+//   stream 0, index = global sample, slot = bounce * 65536 + k, bounce = scatters done so far on the path:
+//       k = 0      : word 0 = Russian-roulette draw (raytrace.cu:230); word 1 = the material's own
+//                    decision draw (metal lobe choice :149, refractive reflect-or-refract :186)
+//       k = 1 + a  : words 0,1,2 = candidate number a of the unit-sphere rejection loop (:7-13)
+// Each draw maps uint32 -> (0, 1] with cuRAND's curand_uniform formula.
+static inline float u01(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
 struct Rng {
     uint32_t key[2];
-    uint32_t ctr[4];
-    uint32_t buf[4];
-    int have;
-    void init(uint64_t seed, uint32_t pixel, uint32_t index, uint32_t stream) {
+    uint32_t pixel, index;
+    void init(uint64_t seed, uint32_t pixel_, uint32_t index_) {
         key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
-        ctr[0] = pixel; ctr[1] = index; ctr[2] = 0; ctr[3] = stream;
-        have = 0;
+        pixel = pixel_; index = index_;
     }
-    uint32_t next_u32() {
-        if (have == 0) { philox4x32_10(ctr, key, buf); ctr[2]++; have = 4; }
-        uint32_t v = buf[4 - have];
-        have--;
-        return v;
+    void block(uint32_t slot, uint32_t stream, uint32_t out[4]) const {
+        const uint32_t ctr[4] = {pixel, index, slot, stream};
+        philox4x32_10(ctr, key, out);
     }
-    // cuRAND's curand_uniform mapping: (0, 1]
-    float uniform() { return (float)next_u32() * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
 };
 
 // ----------------------------------------------------------------------------
@@ -419,14 +420,15 @@ static inline f3 tex2d(const Texture& t, float u, float v) {
 // ----------------------------------------------------------------------------
 // Shading -- cuda/raytrace.cu:7-13, 80-195
 // ----------------------------------------------------------------------------
-static inline f3 random_in_unit_sphere3(Rng& rng) {   // raytrace.cu:7-13
+static inline f3 random_in_unit_sphere3(const Rng& rng, uint32_t bounce) {   // raytrace.cu:7-13
     f3 p;
+    uint32_t attempt = 0;
     do {
-        float a = rng.uniform();
-        float b = rng.uniform();
-        float c = rng.uniform();
-        p = sub(mulf(mk(a, b, c), 2.0f), mk(1.0f, 1.0f, 1.0f));
-    } while (dot3(p, p) >= 1.0f);
+        uint32_t w[4];
+        rng.block(bounce * 65536u + 1u + attempt, 0, w);
+        p = sub(mulf(mk(u01(w[0]), u01(w[1]), u01(w[2])), 2.0f), mk(1.0f, 1.0f, 1.0f));
+        attempt++;
+    } while (dot3(p, p) >= 1.0f && attempt < 65535u);
     return p;
 }
 
@@ -481,12 +483,14 @@ static inline Ray offset_ray(const HitRecord& rec, const f3& dir) {   // raytrac
     return Ray{add(rec.point, mulf(dir, 1e-4f)), dir};
 }
 
-static inline bool material_scatter(Rng& rng, const Material& m, const Ray& r, const HitRecord& rec, Ray& wo, f3& color) {   // raytrace.cu:120-195
+// `decision` is the bounce's material decision draw (word 1 of the bounce's slot-0 block).
+static inline bool material_scatter(const Rng& rng, uint32_t bounce, float decision, const Material& m, const Ray& r,
+                                    const HitRecord& rec, Ray& wo, f3& color) {   // raytrace.cu:120-195
     switch (m.type) {
     case LAMBERTIAN: {
         f3 direction = rec.normal;
         if (dot3(r.direction, rec.normal) > 0.0f) direction = neg(rec.normal);
-        direction = normalize(add(direction, random_in_unit_sphere3(rng)));
+        direction = normalize(add(direction, random_in_unit_sphere3(rng, bounce)));
         float cos_theta = fabsf(dot3(direction, rec.normal));
         color = mul3(color, mulf(rec.color, cos_theta));
         wo = offset_ray(rec, direction);
@@ -495,9 +499,9 @@ static inline bool material_scatter(Rng& rng, const Material& m, const Ray& r, c
     case METAL: {
         f3 normal = rec.normal;
         if (dot3(r.direction, rec.normal) > 0.0f) normal = neg(rec.normal);
-        f3 random = random_in_unit_sphere3(rng);
+        f3 random = random_in_unit_sphere3(rng, bounce);
         f3 direction;
-        if (4.0f * rng.uniform() < 3.0f + m.metal_fuzz) {
+        if (4.0f * decision < 3.0f + m.metal_fuzz) {
             direction = add(normal, random);
             float cos_theta = fabsf(dot3(direction, normal));
             color = mul3(color, mulf(rec.color, cos_theta));
@@ -532,7 +536,7 @@ static inline bool material_scatter(Rng& rng, const Material& m, const Ray& r, c
         float reflect_prob;
         if (refract(r.direction, outward_normal, ni_over_nt, direction)) reflect_prob = schlick(cosine, m.optical_density);
         else reflect_prob = 1.0f;
-        if (rng.uniform() < reflect_prob) direction = reflect(r.direction, rec.normal);
+        if (decision < reflect_prob) direction = reflect(r.direction, rec.normal);
         color = mul3(color, rec.color);
         wo = offset_ray(rec, direction);
         return true;
@@ -544,10 +548,11 @@ static inline bool material_scatter(Rng& rng, const Material& m, const Ray& r, c
 
 // One camera sample -- the body of the spp loop, raytrace.cu:210-244.
 // Returns false when the path ran out of depth (contributes nothing, :243).
-static inline bool trace_path(const Scene& s, Ray ray, Rng& rng, int max_depth, const f3& ambient,
+static inline bool trace_path(const Scene& s, Ray ray, const Rng& rng, int max_depth, const f3& ambient,
                               float russian_roulette, f3& color_out, Counters* cnt) {
     f3 color = mk(1.0f, 1.0f, 1.0f);
     int depth = max_depth;
+    uint32_t bounce = 0;
     while (depth--) {
         HitRecord rec;
         if (!scene_intersect(s, ray, rec, cnt)) { color = mul3(color, ambient); break; }
@@ -555,10 +560,13 @@ static inline bool trace_path(const Scene& s, Ray ray, Rng& rng, int max_depth, 
         triangle_interpolate(s, rec, cnt);
         const Material& m = s.materials[rec.material_id];
         if (m.type == LIGHT) { color = mul3(color, rec.color); break; }
-        else if (rng.uniform() < russian_roulette) {
+        uint32_t w[4];
+        rng.block(bounce * 65536u, 0, w);
+        if (u01(w[0]) < russian_roulette) {
             Ray new_ray;
-            if (!material_scatter(rng, m, ray, rec, new_ray, color)) { color = mul3(color, ambient); break; }
+            if (!material_scatter(rng, bounce, u01(w[1]), m, ray, rec, new_ray, color)) { color = mul3(color, ambient); break; }
             ray = new_ray;
+            bounce++;
         } else { color = mul3(color, ambient); break; }
     }
     if (depth < 0) return false;
@@ -612,9 +620,12 @@ void orc_apply_transform(const float* scale, const float* translate, const float
 
 void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
 
-void orc_uniforms(uint64_t seed, uint32_t pixel, uint32_t index, uint32_t stream, int n, float* out) {
-    Rng r; r.init(seed, pixel, index, stream);
-    for (int i = 0; i < n; i++) out[i] = r.uniform();
+// The four (0,1] draws of one addressed block.
+void orc_uniforms(uint64_t seed, uint32_t pixel, uint32_t index, uint32_t slot, uint32_t stream, float* out4) {
+    Rng r; r.init(seed, pixel, index);
+    uint32_t w[4];
+    r.block(slot, stream, w);
+    for (int i = 0; i < 4; i++) out4[i] = u01(w[i]);
 }
 
 void* orc_scene_create(int n_objects, void** tris, const int* n_tris, void** nodes, const int* n_nodes,
@@ -643,9 +654,10 @@ void orc_primary_rays(const orc_render_params* p, uint32_t batch_index, float* r
     for (int y = 0; y < p->height; y++)
         for (int x = 0; x < p->width; x++) {
             int idx = y * p->width + x;
-            Rng j; j.init(p->seed, (uint32_t)idx, batch_index, 1);
-            float ju = j.uniform(), jv = j.uniform();
-            Ray r = primary_ray(c, p->width, p->height, x, y, ju, jv);
+            Rng j; j.init(p->seed, (uint32_t)idx, batch_index);
+            uint32_t w[4];
+            j.block(0, 1, w);
+            Ray r = primary_ray(c, p->width, p->height, x, y, u01(w[0]), u01(w[1]));
             memcpy(rays + 6 * (size_t)idx, &r, sizeof(r));
         }
 }
@@ -716,12 +728,13 @@ void orc_render(const void* scene, const orc_render_params* p, int first_sample,
                 while (sample < end) {
                     uint32_t batch = (uint32_t)(sample / B);
                     int batch_end = std::min(end, (int)(batch + 1) * B);
-                    Rng j; j.init(p->seed, (uint32_t)idx, batch, 1);
-                    float ju = j.uniform(), jv = j.uniform();
-                    Ray ray = primary_ray(c, p->width, p->height, x, y, ju, jv);
+                    Rng j; j.init(p->seed, (uint32_t)idx, batch);
+                    uint32_t jw[4];
+                    j.block(0, 1, jw);
+                    Ray ray = primary_ray(c, p->width, p->height, x, y, u01(jw[0]), u01(jw[1]));
                     f3 total_color = mk(0.0f, 0.0f, 0.0f);   // raytrace.cu:208
                     for (; sample < batch_end; sample++) {
-                        Rng rng; rng.init(p->seed, (uint32_t)idx, (uint32_t)sample, 0);
+                        Rng rng; rng.init(p->seed, (uint32_t)idx, (uint32_t)sample);
                         f3 color;
                         if (trace_path(s, ray, rng, p->max_depth, ambient, p->russian_roulette, color, &cnt))
                             total_color = add(total_color, color);   // raytrace.cu:244
@@ -768,9 +781,11 @@ void orc_tex2d(const uint8_t* rgba, int w, int h, int n, const float* uv, float*
 
 // Scatter known-answer helper: one material_scatter call with an explicit uniform stream position.
 // in: ray (6), hit point (3), normal (3), color (3), carried color (3); out: new ray (6), color (3); returns 0/1.
-int orc_scatter(const void* material, uint64_t seed, uint32_t pixel, uint32_t sample, const float* ray, const float* point,
+int orc_scatter(const void* material, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, const float* ray, const float* point,
                 const float* normal, const float* hit_color, const float* color_in, float* ray_out, float* color_out) {
-    Rng rng; rng.init(seed, pixel, sample, 0);
+    Rng rng; rng.init(seed, pixel, sample);
+    uint32_t w[4];
+    rng.block(bounce * 65536u, 0, w);
     Ray r; memcpy(&r, ray, sizeof(r));
     HitRecord rec;
     rec.point = mk(point[0], point[1], point[2]);
@@ -778,7 +793,7 @@ int orc_scatter(const void* material, uint64_t seed, uint32_t pixel, uint32_t sa
     rec.color = mk(hit_color[0], hit_color[1], hit_color[2]);
     f3 color = mk(color_in[0], color_in[1], color_in[2]);
     Ray wo{mk(0, 0, 0), mk(0, 0, 0)};
-    bool ok = material_scatter(rng, *(const Material*)material, r, rec, wo, color);
+    bool ok = material_scatter(rng, bounce, u01(w[1]), *(const Material*)material, r, rec, wo, color);
     memcpy(ray_out, &wo, sizeof(wo));
     color_out[0] = color.x; color_out[1] = color.y; color_out[2] = color.z;
     return ok ? 1 : 0;

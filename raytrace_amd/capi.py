@@ -31,9 +31,9 @@ MATERIAL_DTYPE = np.dtype(
 
 MAT_NONE, MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_REFRACTIVE, MAT_REFLECTIVE = range(6)
 
-CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS = range(6)
+CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK = range(7)
 CNT_COUNT = 8
-OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS = 1, 2, 3, 4
+OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS = 1, 2, 3, 4, 5
 
 
 class RtObject(C.Structure):

@@ -59,6 +59,7 @@ struct PathParams {
     unsigned long long* counters;
     int tiles_x, tiles_y;
     int xcd_remap;
+    int lds_slots;                        // stack levels kept in LDS
 };
 
 #define RT_BLOCK 256
@@ -82,21 +83,16 @@ __device__ __forceinline__ v3 vnormalize(v3 a) {                                
 }
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10
+// Philox4x32-10 with addressed draws: counter = (pixel, index, slot, stream), key = seed.
+//   stream 1, index = semantic batch, slot 0: words 0,1 = primary-ray jitter
+//   stream 0, index = global sample, slot = bounce * 65536 + k:
+//       k = 0: word 0 = Russian roulette, word 1 = the material's decision draw
+//       k = 1 + a: words 0..2 = candidate a of the unit-sphere rejection loop
+// No generator state lives in registers, and every lane of a wave calls the generator at the same
+// program points.
 // ---------------------------------------------------------------------------
-struct Rng {
-    uint32_t c0, c1, c2, c3;   // pixel, index, block counter, stream
-    uint32_t b0, b1, b2, b3;
-    int have;
-};
-
-__device__ __forceinline__ void rng_init(Rng& r, uint32_t pixel, uint32_t index, uint32_t stream) {
-    r.c0 = pixel; r.c1 = index; r.c2 = 0; r.c3 = stream; r.have = 0;
-    r.b0 = r.b1 = r.b2 = r.b3 = 0;
-}
-
-__device__ __forceinline__ void philox_block(Rng& r, uint32_t k0, uint32_t k1) {
-    uint32_t x0 = r.c0, x1 = r.c1, x2 = r.c2, x3 = r.c3;
+__device__ __forceinline__ void philox(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k0, uint32_t k1,
+                                       uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
@@ -106,19 +102,11 @@ __device__ __forceinline__ void philox_block(Rng& r, uint32_t k0, uint32_t k1) {
         x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    r.b0 = x0; r.b1 = x1; r.b2 = x2; r.b3 = x3;
-    r.c2++;
-    r.have = 4;
+    o0 = x0; o1 = x1; o2 = x2; o3 = x3;
 }
 
 // cuRAND's uint32 -> (0,1] mapping
-__device__ __forceinline__ float rng_uniform(Rng& r, uint32_t k0, uint32_t k1) {
-    if (r.have == 0) philox_block(r, k0, k1);
-    const uint32_t v = r.b0;
-    r.b0 = r.b1; r.b1 = r.b2; r.b2 = r.b3;
-    r.have--;
-    return (float)v * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
-}
+__device__ __forceinline__ float u01(uint32_t v) { return (float)v * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
 
 // ---------------------------------------------------------------------------
 // traversal
@@ -189,10 +177,15 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 // right child first, leaf left triangle then right, prune on t_near > best t when a node comes off the
 // stack.  The objects hang under the object-level tree, so there is one walk, not one per object.
 // `stack` points at this lane's column of the LDS stack; consecutive slots are `stride` entries apart.
+// The first `lds_slots` stack levels live in LDS; deeper levels (rare: a level is only used while BOTH
+// children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
+#define RT_SPILL_SLOTS 56
+typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, uint2* stack, int stride,
-                                            uint32_t& n_box, uint32_t& n_tri) {
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
+                                            uint32_t& n_box, uint32_t& n_tri, uint32_t& max_sp) {
     h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+    uint2 spill[RT_SPILL_SLOTS];
     int sp = 0;
     uint32_t cur = REF_NONE;
     {
@@ -205,7 +198,9 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, H
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             --sp;
-            const uint2 e = stack[sp * stride];
+            uint2 e;
+            if (sp < lds_slots) { e.x = stack[sp * stride].x; e.y = stack[sp * stride].y; }
+            else e = spill[sp - lds_slots];
             if (!(__uint_as_float(e.y) > h.t)) return e.x;
         }
         return REF_NONE;
@@ -223,7 +218,13 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, H
             // upstream pushes left then right, so the right child is visited first.  A left child whose
             // t_near already exceeds the best t can be dropped now: the best t only shrinks.
             if (hr) {
-                if (hl) { stack[sp * stride] = make_uint2(refl, __float_as_uint(tnl)); sp++; }
+                if (hl) {
+                    const uint2 e = make_uint2(refl, __float_as_uint(tnl));
+                    if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
+                    else spill[sp - lds_slots] = e;
+                    sp++;
+                    if (COUNT) max_sp = max(max_sp, (uint32_t)sp);
+                }
                 cur = refr;
             } else if (hl) {
                 cur = refl;
@@ -243,14 +244,15 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, H
 // ---------------------------------------------------------------------------
 // shading (cuda/raytrace.cu:7-13, 80-195)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ v3 unit_sphere(Rng& rng, uint32_t k0, uint32_t k1) {   // raytrace.cu:7-13
+__device__ __forceinline__ v3 unit_sphere(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t k0, uint32_t k1) {   // raytrace.cu:7-13
     v3 p;
+    uint32_t attempt = 0;
     do {
-        const float a = rng_uniform(rng, k0, k1);
-        const float b = rng_uniform(rng, k0, k1);
-        const float c = rng_uniform(rng, k0, k1);
-        p = mk3(a * 2.0f + (-1.0f), b * 2.0f + (-1.0f), c * 2.0f + (-1.0f));
-    } while (vdot(p, p) >= 1.0f);
+        uint32_t w0, w1, w2, w3;
+        philox(pixel, sample, bounce * 65536u + 1u + attempt, 0u, k0, k1, w0, w1, w2, w3);
+        p = mk3(u01(w0) * 2.0f + (-1.0f), u01(w1) * 2.0f + (-1.0f), u01(w2) * 2.0f + (-1.0f));
+        attempt++;
+    } while (vdot(p, p) >= 1.0f && attempt < 65535u);
     return p;
 }
 
@@ -324,7 +326,7 @@ __device__ __forceinline__ v3 primary_dir(const CameraFrame& cam, int x, int y, 
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams pp) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
-    uint2* stack = lds_stack + threadIdx.x;
+    lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
 
     int id = blockIdx.x;
     if (pp.xcd_remap) {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     const v3 ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
     const v3 cam_pos = mk3(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2]);
 
-    uint32_t n_rays = 0, n_box = 0, n_tri = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
+    uint32_t n_rays = 0, n_box = 0, n_tri = 0, n_shaded = 0, n_tex = 0, n_paths = 0, max_sp = 0;
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -355,8 +357,6 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     v3 prim_dir = mk3(0.0f, 0.0f, 1.0f);
     v3 color = mk3(1.0f, 1.0f, 1.0f);
     int depth = 0;
-    Rng rng;
-    rng_init(rng, 0, 0, 0);
     RayD ray;
     ray_set(ray, cam_pos, prim_dir);
 
@@ -365,16 +365,13 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
         if (bi != jitter_batch) {
             // one jittered primary ray per pixel per semantic batch (camera.cu:35-40, worker.cpp:71-78)
             jitter_batch = bi;
-            Rng j;
-            rng_init(j, (uint32_t)pixel, (uint32_t)bi, 1u);
-            const float ju = rng_uniform(j, k0, k1);
-            const float jv = rng_uniform(j, k0, k1);
-            prim_dir = primary_dir(pp.cam, x, y, ju, jv);
+            uint32_t w0, w1, w2, w3;
+            philox((uint32_t)pixel, (uint32_t)bi, 0u, 1u, k0, k1, w0, w1, w2, w3);
+            prim_dir = primary_dir(pp.cam, x, y, u01(w0), u01(w1));
         }
         ray_set(ray, cam_pos, prim_dir);                 // raytrace.cu:210
         color = mk3(1.0f, 1.0f, 1.0f);                   // :211
         depth = pp.max_depth;                            // :212
-        rng_init(rng, (uint32_t)pixel, (uint32_t)sample, 0u);
     };
 
     if (alive) begin_path();
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
             depth--;
             Hit h;
             n_rays++;
-            closest_hit<COUNT>(sc, ray, h, stack, RT_BLOCK, n_box, n_tri);
+            closest_hit<COUNT>(sc, ray, h, stack, RT_BLOCK, pp.lds_slots, n_box, n_tri, max_sp);
             if (h.tri == REF_NONE) {
                 color = vmul(color, ambient); finished = true;      // raytrace.cu:220-223
             } else {
@@ -417,9 +414,13 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
                 }
                 const v3 rd = mk3(ray.dx, ray.dy, ray.dz);
                 const v3 point = vadd(mk3(ray.ox, ray.oy, ray.oz), vscale(rd, h.t));   // primitives.cuh:17-19
+                const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);         // scatters done so far on this path
+                uint32_t w_rr, w_dec, w2_, w3_;
+                philox((uint32_t)pixel, (uint32_t)sample, bounce * 65536u, 0u, k0, k1, w_rr, w_dec, w2_, w3_);
+                const float decision = u01(w_dec);
                 if (mtype == RT_MAT_LIGHT) {
                     color = vmul(color, hit_color); finished = true;                 // raytrace.cu:226-229
-                } else if (rng_uniform(rng, k0, k1) < pp.rr) {                       // :230
+                } else if (u01(w_rr) < pp.rr) {                                      // :230
                     // ---- material_scatter, raytrace.cu:120-195 ----
                     v3 dir = mk3(0.0f, 0.0f, 0.0f);
                     bool scattered = true;
@@ -427,14 +428,14 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
                     if (mtype == RT_MAT_LAMBERTIAN) {
                         v3 d0 = normal;
                         if (dn > 0.0f) d0 = vneg(normal);
-                        dir = vnormalize(vadd(d0, unit_sphere(rng, k0, k1)));
+                        dir = vnormalize(vadd(d0, unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k0, k1)));
                         const float cos_theta = fabsf(vdot(dir, normal));
                         color = vmul(color, vscale(hit_color, cos_theta));
                     } else if (mtype == RT_MAT_METAL) {
                         v3 nn = normal;
                         if (dn > 0.0f) nn = vneg(normal);
-                        const v3 rnd = unit_sphere(rng, k0, k1);
-                        if (4.0f * rng_uniform(rng, k0, k1) < 3.0f + metal_fuzz) {
+                        const v3 rnd = unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k0, k1);
+                        if (4.0f * decision < 3.0f + metal_fuzz) {
                             dir = vadd(nn, rnd);
                             const float cos_theta = fabsf(vdot(dir, nn));
                             color = vmul(color, vscale(hit_color, cos_theta));
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
                                 reflect_prob = r0 + (1.0f - r0) * powi5(1.0f - cosine);
                             }
                         }
-                        if (rng_uniform(rng, k0, k1) < reflect_prob) dir = reflect3(rd, normal);
+                        if (decision < reflect_prob) dir = reflect3(rd, normal);
                         color = vmul(color, hit_color);
                     } else {
                         scattered = false;
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
         wave_add(pp.counters + RT_CNT_TRI_TESTS, n_tri);
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
         wave_add(pp.counters + RT_CNT_TEX_FETCHES, n_tex);
+        atomicMax(pp.counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
     }
 }
 
@@ -537,20 +539,20 @@ __global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int f
 // ---------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int n_rays, const float* __restrict__ rays,
+__global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int lds_slots, int n_rays, const float* __restrict__ rays,
                                                                int32_t* obj, int32_t* tri, float* t, float* u, float* v,
                                                                unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
-    uint2* stack = lds_stack + threadIdx.x;
+    lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    uint32_t n_box = 0, n_tri = 0, n_r = 0;
+    uint32_t n_box = 0, n_tri = 0, n_r = 0, max_sp = 0;
     if (i < n_rays) {
         RayD r;
         ray_set(r, mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]),
                 mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]));
         Hit h;
         n_r = 1;
-        closest_hit<true>(sc, r, h, stack, RT_BLOCK, n_box, n_tri);
+        closest_hit<true>(sc, r, h, stack, RT_BLOCK, lds_slots, n_box, n_tri, max_sp);
         int o = -1, ti = -1;
         if (h.tri != REF_NONE) { const TriOrigin og = sc.origin[h.tri]; o = og.object; ti = og.triangle; }
         obj[i] = o; tri[i] = ti; t[i] = h.t;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
     wave_add(counters + RT_CNT_RAYS, n_r);
     wave_add(counters + RT_CNT_BOX_TESTS, n_box);
     wave_add(counters + RT_CNT_TRI_TESTS, n_tri);
+    atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void primary_rays_kernel(CameraFrame cam, uint32_t key0, uint32_t key1, uint32_t batch_index,
@@ -567,11 +570,9 @@ __global__ __launch_bounds__(RT_BLOCK) void primary_rays_kernel(CameraFrame cam,
     const int idx = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (idx >= cam.width * cam.height) return;
     const int x = idx % cam.width, y = idx / cam.width;
-    Rng j;
-    rng_init(j, (uint32_t)idx, batch_index, 1u);
-    const float ju = rng_uniform(j, key0, key1);
-    const float jv = rng_uniform(j, key0, key1);
-    const v3 d = primary_dir(cam, x, y, ju, jv);
+    uint32_t w0, w1, w2, w3;
+    philox((uint32_t)idx, batch_index, 0u, 1u, key0, key1, w0, w1, w2, w3);
+    const v3 d = primary_dir(cam, x, y, u01(w0), u01(w1));
     float* o = rays + 6 * (size_t)idx;
     o[0] = cam.pos[0]; o[1] = cam.pos[1]; o[2] = cam.pos[2];
     o[3] = d.x; o[4] = d.y; o[5] = d.z;
@@ -615,8 +616,9 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
-    int opt_chunk = 16;              // samples one lane traces in a row
-    int opt_pass = 64;               // samples per pixel held in the slot buffer at once
+    int opt_lds_slots = 12;          // stack levels kept in LDS (deeper ones spill to private memory)
+    int opt_chunk = 8;               // samples one lane traces in a row
+    int opt_pass = 256;              // samples per pixel held in the slot buffer at once
     float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
     int stack_slots = 1;
@@ -689,6 +691,9 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     switch (option) {
     case RT_OPT_COUNTERS: ctx->opt_counters = value ? 1 : 0; return RT_OK;
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
+    case RT_OPT_LDS_SLOTS:
+        if (value < 1 || value > 32) return fail(RT_ERR_INVALID, "rt_set_option: LDS stack slots must be 1..32");
+        ctx->opt_lds_slots = value; return RT_OK;
     case RT_OPT_CHUNK:
         if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "rt_set_option: chunk must be 1..65536");
         ctx->opt_chunk = value; return RT_OK;
@@ -791,7 +796,9 @@ int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera
     return RT_OK;
 }
 
-static size_t stack_bytes(const rt_context* ctx) { return (size_t)ctx->stack_slots * RT_BLOCK * sizeof(uint2); }
+static int lds_slots(const rt_context* ctx) { return ctx->stack_slots < ctx->opt_lds_slots ? ctx->stack_slots : ctx->opt_lds_slots; }
+static size_t stack_bytes(const rt_context* ctx) { return (size_t)lds_slots(ctx) * RT_BLOCK * sizeof(uint2); }
+static bool stack_fits(const rt_context* ctx) { return ctx->stack_slots <= lds_slots(ctx) + RT_SPILL_SLOTS; }
 
 int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
                 float russian_roulette, float* d_output, void* stream) {
@@ -803,7 +810,7 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     if (first_sample % semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: first_sample must be a multiple of semantic_batch");
     if ((long long)first_sample + spp > 0x7FFFFFFFLL - semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: sample index overflow");
     if (spp == 0) return RT_OK;
-    if (stack_bytes(ctx) > 64 * 1024) return fail(RT_ERR_INVALID, "rt_raytrace: BVH deeper than the LDS stack allows");
+    if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, "rt_raytrace: BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     // slot buffer: one float3 per (sample of the pass, pixel); grown on demand, kept by the context
@@ -830,6 +837,7 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     pp.tiles_y = (ctx->cam.height + 15) / 16;
     pp.xcd_remap = ctx->opt_xcd;
     pp.chunk = ctx->opt_chunk;
+    pp.lds_slots = lds_slots(ctx);
     for (int done = 0; done < spp; done += pass) {
         pp.first_sample = first_sample + done;
         pp.n_samples = spp - done < pass ? spp - done : pass;
@@ -876,10 +884,10 @@ int rt_closest_hit(rt_context* ctx, int n_rays, const float* d_rays, int32_t* d_
         return fail(RT_ERR_INVALID, "rt_closest_hit: bad argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_closest_hit: no scene uploaded");
     if (n_rays == 0) return RT_OK;
-    if (stack_bytes(ctx) > 64 * 1024) return fail(RT_ERR_INVALID, "rt_closest_hit: BVH deeper than the LDS stack allows");
+    if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, "rt_closest_hit: BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(closest_hit_kernel, dim3((n_rays + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), stack_bytes(ctx), (hipStream_t)stream,
-                       ctx->dev, n_rays, d_rays, d_object, d_triangle, d_t, d_u, d_v, ctx->d_counters);
+                       ctx->dev, lds_slots(ctx), n_rays, d_rays, d_object, d_triangle, d_t, d_u, d_v, ctx->d_counters);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

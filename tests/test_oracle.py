@@ -32,16 +32,17 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_uniform_mapping_is_curand_half_open_interval():
-    u = orc.uniforms(0x5EED0001, 7, 3, 0, 100000)
-    assert u.min() > 0.0 and u.max() <= 1.0
-    assert abs(float(u.mean()) - 0.5) < 5e-3
-    # stream words come from consecutive counter blocks
-    raw = orc.philox([7, 3, 0, 0], [0x5EED0001, 0])
-    expect = (raw.astype(np.float32) * np.float32(2.3283064365386963e-10) + np.float32(1.1641532182693481e-10)).astype(np.float32)
-    assert same_f32(u[:4], expect)
-    raw1 = orc.philox([7, 3, 1, 0], [0x5EED0001, 0])
-    assert bits(u[4])[()] == bits((np.float32(raw1[0]) * np.float32(2.3283064365386963e-10) + np.float32(1.1641532182693481e-10)).astype(np.float32))[()]
+def test_uniform_mapping_and_draw_addressing():
+    # every draw has a counter address (pixel, index, slot, stream); uint32 -> (0, 1] is cuRAND's mapping
+    c1, c2 = np.float32(2.3283064365386963e-10), np.float32(1.1641532182693481e-10)
+    for (pixel, index, slot, stream) in [(7, 3, 0, 0), (7, 3, 65536 + 1, 0), (123456, 9, 0, 1)]:
+        raw = orc.philox([pixel, index, slot, stream], [0x5EED0001, 0])
+        expect = (raw.astype(np.float32) * c1 + c2).astype(np.float32)
+        assert same_f32(orc.uniforms(0x5EED0001, pixel, index, slot, stream), expect)
+    # the extremes of the mapping: 0 -> 2^-33 (> 0), 2^32-1 -> 1.0 exactly
+    assert (np.float32(0) * c1 + c2) > 0 and (np.float32(4294967295) * c1 + c2) == np.float32(1.0)
+    u = np.concatenate([orc.uniforms(1, p, 0, 0, 0) for p in range(5000)])
+    assert u.min() > 0.0 and u.max() <= 1.0 and abs(float(u.mean()) - 0.5) < 1e-2
 
 
 def _plane_object():
