@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = library default)")
     ap.add_argument("--pass-spp", type=int, default=0, help="samples per buffered pass (0 = library default)")
     ap.add_argument("--lds-slots", type=int, default=0, help="traversal stack levels in LDS (0 = library default)")
+    ap.add_argument("--mode", default="", choices=["", "megakernel", "wavefront"], help="path-state design (default: library default)")
+    ap.add_argument("--wf-log2", type=int, default=0, help="wavefront pool capacity, log2 paths (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +99,10 @@ def main():
         ctx.set_option(capi.OPT_PASS, args.pass_spp)
     if args.lds_slots:
         ctx.set_option(capi.OPT_LDS_SLOTS, args.lds_slots)
+    if args.mode:
+        ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT if args.mode == "wavefront" else capi.MODE_MEGAKERNEL)
+    if args.wf_log2:
+        ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, args.wf_log2)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height

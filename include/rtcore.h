@@ -113,7 +113,11 @@ enum {
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
     RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 256);
                                  scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
-    RT_OPT_LDS_SLOTS = 5      /* traversal-stack levels kept in LDS (default 12); deeper levels spill to private memory */
+    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 12); deeper levels spill to private memory */
+    RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths (default); 1 = wavefront: path state in HBM,
+                                 one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
+                                 In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
+    RT_OPT_WF_CAPACITY_LOG2 = 7 /* wavefront pool size = 2^value paths (default 22; 7 * 16 bytes of HBM per path) */
 };
 
 const char* rt_last_error(void);

@@ -33,7 +33,8 @@ MAT_NONE, MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_REFRACTIVE, MAT_REFLECTIVE =
 
 CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK = range(7)
 CNT_COUNT = 8
-OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS = 1, 2, 3, 4, 5
+OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS, OPT_MODE, OPT_WF_CAPACITY_LOG2 = 1, 2, 3, 4, 5, 6, 7
+MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 
 
 class RtObject(C.Structure):

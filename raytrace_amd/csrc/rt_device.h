@@ -1,0 +1,410 @@
+// rt_device.h -- device-side building blocks shared by every kernel: float3 math in upstream's operand
+// order, the addressed Philox generator, the slab / Moller-Trumbore tests, the closest-hit walk and the
+// shading step.  Compiled with -ffp-contract=off.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include "rt_host.h"
+
+using namespace rtc;
+
+// ---------------------------------------------------------------------------
+// device-side scene view and parameters
+// ---------------------------------------------------------------------------
+struct SceneDev {
+    ChildRec root;            // box + reference of the whole scene (root of the object-level tree)
+    const Node64* nodes;
+    const TriIsect* isect;
+    const TriShade* shade;
+    const TriOrigin* origin;
+    const MatDev* mats;
+    const TexDev* tex;
+    const uint32_t* texels;
+    int n_materials;
+};
+
+struct PathParams {
+    CameraFrame cam;
+    int n_pixel;
+    int first_sample, n_samples, batch;   // this pass: global samples [first_sample, first_sample + n_samples)
+    int chunk, n_chunks;                  // samples per lane; lanes (chunks) per pixel in this pass
+    int max_depth;
+    float ambient[3];
+    float rr;
+    uint32_t key0, key1;
+    float* slots;                         // [n_samples][n_pixel][3]: radiance of each path of the pass
+    unsigned long long* counters;
+    int tiles_x, tiles_y;
+    int xcd_remap;
+    int lds_slots;                        // stack levels kept in LDS
+};
+
+#define RT_BLOCK 256
+#define RT_INF __builtin_inff()
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 vadd(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return mk3(a.x + (-b.x), a.y + (-b.y), a.z + (-b.z)); }
+__device__ __forceinline__ v3 vscale(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 vmul(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 vneg(v3 a) { return vscale(a, -1.0f); }                       // common.cuh:126-130
+__device__ __forceinline__ float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 vcross(v3 a, v3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 vnormalize(v3 a) {                                              // common.cuh:75-78
+    float n = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return mk3(a.x / n, a.y / n, a.z / n);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 with addressed draws: counter = (pixel, index, slot, stream), key = seed.
+//   stream 1, index = semantic batch, slot 0: words 0,1 = primary-ray jitter
+//   stream 0, index = global sample, slot = bounce * 65536 + k:
+//       k = 0: word 0 = Russian roulette, word 1 = the material's decision draw
+//       k = 1 + a: words 0..2 = candidate a of the unit-sphere rejection loop
+// No generator state lives in registers, and every lane of a wave calls the generator at the same
+// program points.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k0, uint32_t k1,
+                                       uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+        const uint32_t n0 = hi1 ^ x1 ^ k0;
+        const uint32_t n2 = hi0 ^ x3 ^ k1;
+        x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = x0; o1 = x1; o2 = x2; o3 = x3;
+}
+
+// cuRAND's uint32 -> (0,1] mapping
+__device__ __forceinline__ float u01(uint32_t v) { return (float)v * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
+// ---------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------
+struct RayD {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float ix, iy, iz;    // 1/d, hoisted out of include/bvh.h:43
+};
+
+__device__ __forceinline__ void ray_set(RayD& r, v3 o, v3 d) {
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.ix = 1.0f / d.x; r.iy = 1.0f / d.y; r.iz = 1.0f / d.z;
+}
+
+// include/bvh.h:39-58.  The per-axis early exit there is equivalent to one final
+// t0 > t1 test because t0 never decreases and t1 never increases.
+__device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                     const RayD& r, float& t_near) {
+    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
+    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
+    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+    float t0 = fmaxf(-RT_INF, nx ? bx : ax);
+    float t1 = fminf(RT_INF, nx ? ax : bx);
+    t0 = fmaxf(t0, ny ? by : ay);
+    t1 = fminf(t1, ny ? ay : by);
+    t0 = fmaxf(t0, nz ? bz : az);
+    t1 = fminf(t1, nz ? az : bz);
+    t_near = t0;
+    return !(t0 > t1) && (t1 > 0.0f);
+}
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri;      // packed triangle index, REF_NONE when nothing was hit
+};
+
+// cuda/raytrace.cu:24-42 on a packed record (e1, e2 precomputed).  Rejections keep
+// upstream's comparison polarity so that NaNs fall the same way.
+__device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint32_t p, const RayD& r, Hit& h) {
+    const float4* q = reinterpret_cast<const float4*>(tris + p);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
+    const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+    const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+    const float px = r.dy * e2z - r.dz * e2y;
+    const float py = r.dz * e2x - r.dx * e2z;
+    const float pz = r.dx * e2y - r.dy * e2x;
+    const float det = e1x * px + e1y * py + e1z * pz;
+    bool rej = (det > -1e-6f) && (det < 1e-6f);
+    const float inv_det = 1.0f / det;
+    const float tx = r.ox + (-v0x), ty = r.oy + (-v0y), tz = r.oz + (-v0z);
+    const float u = (tx * px + ty * py + tz * pz) * inv_det;
+    rej = rej || (u < 0.0f) || (u > 1.0f);
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * inv_det;
+    rej = rej || (v < 0.0f) || (u + v > 1.0f);
+    const float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+    rej = rej || (t < 0.0f) || (t > h.t);
+    if (!rej) { h.t = t; h.u = u; h.v = v; h.tri = p; }
+}
+
+// Closest hit over the whole scene in upstream's visiting order (cuda/raytrace.cu:44-78, 214-219):
+// right child first, leaf left triangle then right, prune on t_near > best t when a node comes off the
+// stack.  The objects hang under the object-level tree, so there is one walk, not one per object.
+// `stack` points at this lane's column of the LDS stack; consecutive slots are `stride` entries apart.
+// The first `lds_slots` stack levels live in LDS; deeper levels (rare: a level is only used while BOTH
+// children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
+#define RT_SPILL_SLOTS 56
+typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
+                                            uint32_t& n_box, uint32_t& n_tri, uint32_t& max_sp) {
+    h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+    uint2 spill[RT_SPILL_SLOTS];
+    int sp = 0;
+    uint32_t cur = REF_NONE;
+    {
+        float tn;
+        if (COUNT) n_box++;
+        if (slab(sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0], sc.root.bmax[1], sc.root.bmax[2], r, tn))
+            cur = sc.root.ref;
+    }
+    // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            --sp;
+            uint2 e;
+            if (sp < lds_slots) { e.x = stack[sp * stride].x; e.y = stack[sp * stride].y; }
+            else e = spill[sp - lds_slots];
+            if (!(__uint_as_float(e.y) > h.t)) return e.x;
+        }
+        return REF_NONE;
+    };
+    for (;;) {
+        // inner nodes: one 64-byte record decides both children.  REF_NONE has the leaf bit set and ends the loop.
+        while (!(cur & REF_LEAF)) {
+            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+            float tnl, tnr;
+            if (COUNT) n_box += 2;
+            const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
+            const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
+            const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
+            // upstream pushes left then right, so the right child is visited first.  A left child whose
+            // t_near already exceeds the best t can be dropped now: the best t only shrinks.
+            if (hr) {
+                if (hl) {
+                    const uint2 e = make_uint2(refl, __float_as_uint(tnl));
+                    if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
+                    else spill[sp - lds_slots] = e;
+                    sp++;
+                    if (COUNT) max_sp = max(max_sp, (uint32_t)sp);
+                }
+                cur = refr;
+            } else if (hl) {
+                cur = refl;
+            } else {
+                cur = pop();
+            }
+        }
+        if (cur == REF_NONE) break;
+        const uint32_t p = cur & REF_MASK;
+        if (COUNT) n_tri += (cur & REF_PAIR) ? 2u : 1u;
+        tri_test(sc.isect, p, r, h);
+        if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
+        cur = pop();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shading (cuda/raytrace.cu:7-13, 80-195)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ v3 unit_sphere(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t k0, uint32_t k1) {   // raytrace.cu:7-13
+    v3 p;
+    uint32_t attempt = 0;
+    do {
+        uint32_t w0, w1, w2, w3;
+        philox(pixel, sample, bounce * 65536u + 1u + attempt, 0u, k0, k1, w0, w1, w2, w3);
+        p = mk3(u01(w0) * 2.0f + (-1.0f), u01(w1) * 2.0f + (-1.0f), u01(w2) * 2.0f + (-1.0f));
+        attempt++;
+    } while (vdot(p, p) >= 1.0f && attempt < 65535u);
+    return p;
+}
+
+__device__ __forceinline__ v3 reflect3(v3 v, v3 n) { return vsub(v, vscale(n, 2.0f * vdot(v, n))); }   // raytrace.cu:98-100
+
+__device__ __forceinline__ void texel_rgb(const SceneDev& sc, const TexDev& t, int i, int j, float& r, float& g, float& b) {
+    if (i < 0 || j < 0 || i >= t.width || j >= t.height) { r = g = b = 0.0f; return; }   // border addressing
+    const uint32_t px = sc.texels[t.offset + (uint32_t)j * (uint32_t)t.width + (uint32_t)i];
+    r = (float)(px & 0xFFu) / 255.0f;
+    g = (float)((px >> 8) & 0xFFu) / 255.0f;
+    b = (float)((px >> 16) & 0xFFu) / 255.0f;
+}
+
+// Software stand-in for tex2D<float4> with normalized coordinates, linear filter,
+// border addressing and 8-bit fractional weights (csrc/sceneloader.cpp:240-246).
+__device__ __forceinline__ v3 tex_fetch(const SceneDev& sc, int tex_index, float u, float v) {
+    const TexDev t = sc.tex[tex_index];
+    const float xb = u * (float)t.width - 0.5f;
+    const float yb = v * (float)t.height - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    const float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f;
+    const float b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
+    fi = fminf(fmaxf(fi, -2.0f), (float)t.width + 1.0f);
+    fj = fminf(fmaxf(fj, -2.0f), (float)t.height + 1.0f);
+    if (!(fi == fi)) fi = -2.0f;
+    if (!(fj == fj)) fj = -2.0f;
+    const int i = (int)fi, j = (int)fj;
+    float r00, g00, b00, r10, g10, b10, r01, g01, b01, r11, g11, b11;
+    texel_rgb(sc, t, i, j, r00, g00, b00);
+    texel_rgb(sc, t, i + 1, j, r10, g10, b10);
+    texel_rgb(sc, t, i, j + 1, r01, g01, b01);
+    texel_rgb(sc, t, i + 1, j + 1, r11, g11, b11);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return mk3(w00 * r00 + w10 * r10 + w01 * r01 + w11 * r11,
+               w00 * g00 + w10 * g10 + w01 * g01 + w11 * g11,
+               w00 * b00 + w10 * b10 + w01 * b01 + w11 * b11);
+}
+
+// pow(float, int) in CUDA device code is repeated squaring in binary32; exponent 5 -> a * ((a*a)*(a*a))
+__device__ __forceinline__ float powi5(float a) { const float a2 = a * a; const float a4 = a2 * a2; return a * a4; }
+
+// ---------------------------------------------------------------------------
+// wave-aggregated counters
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+}
+
+// ---------------------------------------------------------------------------
+// camera
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ v3 primary_dir(const CameraFrame& cam, int x, int y, float ju, float jv) {   // camera.cu:35-39
+    const float u = ((float)x + ju) / (float)cam.width;
+    const float v = ((float)y + jv) / (float)cam.height;
+    const v3 ll = mk3(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
+    const v3 dx = mk3(cam.dx[0], cam.dx[1], cam.dx[2]);
+    const v3 dy = mk3(cam.dy[0], cam.dy[1], cam.dy[2]);
+    return vnormalize(vadd(vadd(ll, vscale(dx, u)), vscale(dy, v)));
+}
+
+// ---------------------------------------------------------------------------
+// one iteration of upstream's depth loop after the closest-hit query (cuda/raytrace.cu:220-241):
+// miss / light / Russian roulette / scatter.  Returns true when the path has ended (`color` is final),
+// false when it goes on along `ray`.  `bounce` = scatters already done on this path (addresses the draws).
+// ---------------------------------------------------------------------------
+struct ShadeConst {
+    v3 ambient;
+    float rr;
+    uint32_t k0, k1;
+};
+
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& k, RayD& ray, const Hit& h, uint32_t pixel,
+                                          uint32_t sample, uint32_t bounce, v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
+    if (h.tri == REF_NONE) {
+        color = vmul(color, k.ambient); return true;      // raytrace.cu:220-223
+    } else {
+        if (COUNT) n_shaded++;
+        // ---- triangle_interpolate, raytrace.cu:80-96 ----
+        const float4* sq = reinterpret_cast<const float4*>(sc.shade + h.tri);
+        const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
+        const float u = h.u, v = h.v;
+        const float w = 1.0f - u - v;
+        const v3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+        const v3 normal = vnormalize(vadd(vadd(vscale(n0, w), vscale(n1, u)), vscale(n2, v)));
+        const int mat_id = __float_as_int(s3.w);
+        const float4* mq = reinterpret_cast<const float4*>(sc.mats + mat_id);
+        const float4 m0 = mq[0], m1 = mq[1];
+        const int mtype = __float_as_int(m0.x);
+        const float optical_density = m1.x, metal_fuzz = m1.y;
+        const int mtex = __float_as_int(m1.z);
+        v3 hit_color;
+        if (mtex < 0) {
+            hit_color = mk3(m0.y, m0.z, m0.w);
+        } else {
+            const float tcx = w * s2.y + u * s2.w + v * s3.y;
+            const float tcy = w * s2.z + u * s3.x + v * s3.z;
+            if (COUNT) n_tex++;
+            hit_color = tex_fetch(sc, mtex, tcx, tcy);
+        }
+        const v3 rd = mk3(ray.dx, ray.dy, ray.dz);
+        const v3 point = vadd(mk3(ray.ox, ray.oy, ray.oz), vscale(rd, h.t));   // primitives.cuh:17-19
+            uint32_t w_rr, w_dec, w2_, w3_;
+        philox((uint32_t)pixel, (uint32_t)sample, bounce * 65536u, 0u, k.k0, k.k1, w_rr, w_dec, w2_, w3_);
+        const float decision = u01(w_dec);
+        if (mtype == RT_MAT_LIGHT) {
+            color = vmul(color, hit_color); return true;                 // raytrace.cu:226-229
+        } else if (u01(w_rr) < k.rr) {                                      // :230
+            // ---- material_scatter, raytrace.cu:120-195 ----
+            v3 dir = mk3(0.0f, 0.0f, 0.0f);
+            bool scattered = true;
+            const float dn = vdot(rd, normal);
+            if (mtype == RT_MAT_LAMBERTIAN) {
+                v3 d0 = normal;
+                if (dn > 0.0f) d0 = vneg(normal);
+                dir = vnormalize(vadd(d0, unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k.k0, k.k1)));
+                const float cos_theta = fabsf(vdot(dir, normal));
+                color = vmul(color, vscale(hit_color, cos_theta));
+            } else if (mtype == RT_MAT_METAL) {
+                v3 nn = normal;
+                if (dn > 0.0f) nn = vneg(normal);
+                const v3 rnd = unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k.k0, k.k1);
+                if (4.0f * decision < 3.0f + metal_fuzz) {
+                    dir = vadd(nn, rnd);
+                    const float cos_theta = fabsf(vdot(dir, nn));
+                    color = vmul(color, vscale(hit_color, cos_theta));
+                } else {
+                    dir = vadd(vnormalize(reflect3(rd, nn)), vscale(rnd, metal_fuzz));
+                }
+            } else if (mtype == RT_MAT_REFLECTIVE) {
+                dir = reflect3(rd, normal);
+                color = vmul(color, hit_color);
+            } else if (mtype == RT_MAT_REFRACTIVE) {
+                v3 outward;
+                float ni_over_nt, cosine;
+                if (dn > 0.0f) {
+                    outward = vneg(normal);
+                    ni_over_nt = optical_density;
+                    cosine = optical_density * dn;
+                } else {
+                    outward = normal;
+                    ni_over_nt = 1.0f / optical_density;
+                    cosine = -dn;
+                }
+                float reflect_prob = 1.0f;
+                {   // refract, raytrace.cu:102-110
+                    const float dt = vdot(rd, outward);
+                    const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+                    if (disc > 0.0f) {
+                        dir = vsub(vscale(vsub(rd, vscale(outward, dt)), ni_over_nt), vscale(outward, sqrtf(disc)));
+                        float r0 = (1.0f - optical_density) / (1.0f + optical_density);   // schlick, :112-116
+                        r0 = r0 * r0;
+                        reflect_prob = r0 + (1.0f - r0) * powi5(1.0f - cosine);
+                    }
+                }
+                if (decision < reflect_prob) dir = reflect3(rd, normal);
+                color = vmul(color, hit_color);
+            } else {
+                scattered = false;
+            }
+            if (scattered) {
+                ray_set(ray, vadd(point, vscale(dir, 1e-4f)), dir);         // raytrace.cu:118
+            } else {
+                color = vmul(color, k.ambient); return true;             // :232-235
+            }
+        } else {
+            color = vmul(color, k.ambient); return true;                 // :238-241
+        }
+    }
+    return false;
+}
+
+#endif

@@ -27,294 +27,7 @@
 #include <string>
 #include <vector>
 
-#include "rt_host.h"
-
-using namespace rtc;
-
-// ---------------------------------------------------------------------------
-// device-side scene view and parameters
-// ---------------------------------------------------------------------------
-struct SceneDev {
-    ChildRec root;            // box + reference of the whole scene (root of the object-level tree)
-    const Node64* nodes;
-    const TriIsect* isect;
-    const TriShade* shade;
-    const TriOrigin* origin;
-    const MatDev* mats;
-    const TexDev* tex;
-    const uint32_t* texels;
-    int n_materials;
-};
-
-struct PathParams {
-    CameraFrame cam;
-    int n_pixel;
-    int first_sample, n_samples, batch;   // this pass: global samples [first_sample, first_sample + n_samples)
-    int chunk, n_chunks;                  // samples per lane; lanes (chunks) per pixel in this pass
-    int max_depth;
-    float ambient[3];
-    float rr;
-    uint32_t key0, key1;
-    float* slots;                         // [n_samples][n_pixel][3]: radiance of each path of the pass
-    unsigned long long* counters;
-    int tiles_x, tiles_y;
-    int xcd_remap;
-    int lds_slots;                        // stack levels kept in LDS
-};
-
-#define RT_BLOCK 256
-#define RT_INF __builtin_inff()
-
-struct v3 { float x, y, z; };
-
-__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ v3 vadd(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return mk3(a.x + (-b.x), a.y + (-b.y), a.z + (-b.z)); }
-__device__ __forceinline__ v3 vscale(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ v3 vmul(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ v3 vneg(v3 a) { return vscale(a, -1.0f); }                       // common.cuh:126-130
-__device__ __forceinline__ float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ v3 vcross(v3 a, v3 b) {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ v3 vnormalize(v3 a) {                                              // common.cuh:75-78
-    float n = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
-    return mk3(a.x / n, a.y / n, a.z / n);
-}
-
-// ---------------------------------------------------------------------------
-// Philox4x32-10 with addressed draws: counter = (pixel, index, slot, stream), key = seed.
-//   stream 1, index = semantic batch, slot 0: words 0,1 = primary-ray jitter
-//   stream 0, index = global sample, slot = bounce * 65536 + k:
-//       k = 0: word 0 = Russian roulette, word 1 = the material's decision draw
-//       k = 1 + a: words 0..2 = candidate a of the unit-sphere rejection loop
-// No generator state lives in registers, and every lane of a wave calls the generator at the same
-// program points.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k0, uint32_t k1,
-                                       uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
-        const uint32_t n0 = hi1 ^ x1 ^ k0;
-        const uint32_t n2 = hi0 ^ x3 ^ k1;
-        x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o0 = x0; o1 = x1; o2 = x2; o3 = x3;
-}
-
-// cuRAND's uint32 -> (0,1] mapping
-__device__ __forceinline__ float u01(uint32_t v) { return (float)v * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
-
-// ---------------------------------------------------------------------------
-// traversal
-// ---------------------------------------------------------------------------
-struct RayD {
-    float ox, oy, oz;
-    float dx, dy, dz;
-    float ix, iy, iz;    // 1/d, hoisted out of include/bvh.h:43
-};
-
-__device__ __forceinline__ void ray_set(RayD& r, v3 o, v3 d) {
-    r.ox = o.x; r.oy = o.y; r.oz = o.z;
-    r.dx = d.x; r.dy = d.y; r.dz = d.z;
-    r.ix = 1.0f / d.x; r.iy = 1.0f / d.y; r.iz = 1.0f / d.z;
-}
-
-// include/bvh.h:39-58.  The per-axis early exit there is equivalent to one final
-// t0 > t1 test because t0 never decreases and t1 never increases.
-__device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                     const RayD& r, float& t_near) {
-    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
-    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
-    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
-    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
-    float t0 = fmaxf(-RT_INF, nx ? bx : ax);
-    float t1 = fminf(RT_INF, nx ? ax : bx);
-    t0 = fmaxf(t0, ny ? by : ay);
-    t1 = fminf(t1, ny ? ay : by);
-    t0 = fmaxf(t0, nz ? bz : az);
-    t1 = fminf(t1, nz ? az : bz);
-    t_near = t0;
-    return !(t0 > t1) && (t1 > 0.0f);
-}
-
-struct Hit {
-    float t, u, v;
-    uint32_t tri;      // packed triangle index, REF_NONE when nothing was hit
-};
-
-// cuda/raytrace.cu:24-42 on a packed record (e1, e2 precomputed).  Rejections keep
-// upstream's comparison polarity so that NaNs fall the same way.
-__device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint32_t p, const RayD& r, Hit& h) {
-    const float4* q = reinterpret_cast<const float4*>(tris + p);
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-    const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
-    const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
-    const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
-    const float px = r.dy * e2z - r.dz * e2y;
-    const float py = r.dz * e2x - r.dx * e2z;
-    const float pz = r.dx * e2y - r.dy * e2x;
-    const float det = e1x * px + e1y * py + e1z * pz;
-    bool rej = (det > -1e-6f) && (det < 1e-6f);
-    const float inv_det = 1.0f / det;
-    const float tx = r.ox + (-v0x), ty = r.oy + (-v0y), tz = r.oz + (-v0z);
-    const float u = (tx * px + ty * py + tz * pz) * inv_det;
-    rej = rej || (u < 0.0f) || (u > 1.0f);
-    const float qx = ty * e1z - tz * e1y;
-    const float qy = tz * e1x - tx * e1z;
-    const float qz = tx * e1y - ty * e1x;
-    const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * inv_det;
-    rej = rej || (v < 0.0f) || (u + v > 1.0f);
-    const float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
-    rej = rej || (t < 0.0f) || (t > h.t);
-    if (!rej) { h.t = t; h.u = u; h.v = v; h.tri = p; }
-}
-
-// Closest hit over the whole scene in upstream's visiting order (cuda/raytrace.cu:44-78, 214-219):
-// right child first, leaf left triangle then right, prune on t_near > best t when a node comes off the
-// stack.  The objects hang under the object-level tree, so there is one walk, not one per object.
-// `stack` points at this lane's column of the LDS stack; consecutive slots are `stride` entries apart.
-// The first `lds_slots` stack levels live in LDS; deeper levels (rare: a level is only used while BOTH
-// children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
-#define RT_SPILL_SLOTS 56
-typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
-                                            uint32_t& n_box, uint32_t& n_tri, uint32_t& max_sp) {
-    h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-    uint2 spill[RT_SPILL_SLOTS];
-    int sp = 0;
-    uint32_t cur = REF_NONE;
-    {
-        float tn;
-        if (COUNT) n_box++;
-        if (slab(sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0], sc.root.bmax[1], sc.root.bmax[2], r, tn))
-            cur = sc.root.ref;
-    }
-    // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
-    auto pop = [&]() -> uint32_t {
-        while (sp > 0) {
-            --sp;
-            uint2 e;
-            if (sp < lds_slots) { e.x = stack[sp * stride].x; e.y = stack[sp * stride].y; }
-            else e = spill[sp - lds_slots];
-            if (!(__uint_as_float(e.y) > h.t)) return e.x;
-        }
-        return REF_NONE;
-    };
-    for (;;) {
-        // inner nodes: one 64-byte record decides both children.  REF_NONE has the leaf bit set and ends the loop.
-        while (!(cur & REF_LEAF)) {
-            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-            const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-            float tnl, tnr;
-            if (COUNT) n_box += 2;
-            const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
-            const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
-            const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
-            // upstream pushes left then right, so the right child is visited first.  A left child whose
-            // t_near already exceeds the best t can be dropped now: the best t only shrinks.
-            if (hr) {
-                if (hl) {
-                    const uint2 e = make_uint2(refl, __float_as_uint(tnl));
-                    if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
-                    else spill[sp - lds_slots] = e;
-                    sp++;
-                    if (COUNT) max_sp = max(max_sp, (uint32_t)sp);
-                }
-                cur = refr;
-            } else if (hl) {
-                cur = refl;
-            } else {
-                cur = pop();
-            }
-        }
-        if (cur == REF_NONE) break;
-        const uint32_t p = cur & REF_MASK;
-        if (COUNT) n_tri += (cur & REF_PAIR) ? 2u : 1u;
-        tri_test(sc.isect, p, r, h);
-        if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
-        cur = pop();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// shading (cuda/raytrace.cu:7-13, 80-195)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ v3 unit_sphere(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t k0, uint32_t k1) {   // raytrace.cu:7-13
-    v3 p;
-    uint32_t attempt = 0;
-    do {
-        uint32_t w0, w1, w2, w3;
-        philox(pixel, sample, bounce * 65536u + 1u + attempt, 0u, k0, k1, w0, w1, w2, w3);
-        p = mk3(u01(w0) * 2.0f + (-1.0f), u01(w1) * 2.0f + (-1.0f), u01(w2) * 2.0f + (-1.0f));
-        attempt++;
-    } while (vdot(p, p) >= 1.0f && attempt < 65535u);
-    return p;
-}
-
-__device__ __forceinline__ v3 reflect3(v3 v, v3 n) { return vsub(v, vscale(n, 2.0f * vdot(v, n))); }   // raytrace.cu:98-100
-
-__device__ __forceinline__ void texel_rgb(const SceneDev& sc, const TexDev& t, int i, int j, float& r, float& g, float& b) {
-    if (i < 0 || j < 0 || i >= t.width || j >= t.height) { r = g = b = 0.0f; return; }   // border addressing
-    const uint32_t px = sc.texels[t.offset + (uint32_t)j * (uint32_t)t.width + (uint32_t)i];
-    r = (float)(px & 0xFFu) / 255.0f;
-    g = (float)((px >> 8) & 0xFFu) / 255.0f;
-    b = (float)((px >> 16) & 0xFFu) / 255.0f;
-}
-
-// Software stand-in for tex2D<float4> with normalized coordinates, linear filter,
-// border addressing and 8-bit fractional weights (csrc/sceneloader.cpp:240-246).
-__device__ __forceinline__ v3 tex_fetch(const SceneDev& sc, int tex_index, float u, float v) {
-    const TexDev t = sc.tex[tex_index];
-    const float xb = u * (float)t.width - 0.5f;
-    const float yb = v * (float)t.height - 0.5f;
-    float fi = floorf(xb), fj = floorf(yb);
-    const float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f;
-    const float b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
-    fi = fminf(fmaxf(fi, -2.0f), (float)t.width + 1.0f);
-    fj = fminf(fmaxf(fj, -2.0f), (float)t.height + 1.0f);
-    if (!(fi == fi)) fi = -2.0f;
-    if (!(fj == fj)) fj = -2.0f;
-    const int i = (int)fi, j = (int)fj;
-    float r00, g00, b00, r10, g10, b10, r01, g01, b01, r11, g11, b11;
-    texel_rgb(sc, t, i, j, r00, g00, b00);
-    texel_rgb(sc, t, i + 1, j, r10, g10, b10);
-    texel_rgb(sc, t, i, j + 1, r01, g01, b01);
-    texel_rgb(sc, t, i + 1, j + 1, r11, g11, b11);
-    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    return mk3(w00 * r00 + w10 * r10 + w01 * r01 + w11 * r11,
-               w00 * g00 + w10 * g10 + w01 * g01 + w11 * g11,
-               w00 * b00 + w10 * b10 + w01 * b01 + w11 * b11);
-}
-
-// pow(float, int) in CUDA device code is repeated squaring in binary32; exponent 5 -> a * ((a*a)*(a*a))
-__device__ __forceinline__ float powi5(float a) { const float a2 = a * a; const float a4 = a2 * a2; return a * a4; }
-
-// ---------------------------------------------------------------------------
-// wave-aggregated counters
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v) {
-    unsigned long long s = v;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
-}
-
-// ---------------------------------------------------------------------------
-// camera
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ v3 primary_dir(const CameraFrame& cam, int x, int y, float ju, float jv) {   // camera.cu:35-39
-    const float u = ((float)x + ju) / (float)cam.width;
-    const float v = ((float)y + jv) / (float)cam.height;
-    const v3 ll = mk3(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
-    const v3 dx = mk3(cam.dx[0], cam.dx[1], cam.dx[2]);
-    const v3 dy = mk3(cam.dy[0], cam.dy[1], cam.dy[2]);
-    return vnormalize(vadd(vadd(ll, vscale(dx, u)), vscale(dy, v)));
-}
+#include "rt_device.h"
 
 // ---------------------------------------------------------------------------
 // the path kernel
@@ -343,7 +56,9 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     const bool inside = (x < pp.cam.width) && (y < pp.cam.height);
     const int pixel = y * pp.cam.width + x;
     const uint32_t k0 = pp.key0, k1 = pp.key1;
-    const v3 ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
+    ShadeConst sk;
+    sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
+    sk.rr = pp.rr; sk.k0 = k0; sk.k1 = k1;
     const v3 cam_pos = mk3(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2]);
 
     uint32_t n_rays = 0, n_box = 0, n_tri = 0, n_shaded = 0, n_tex = 0, n_paths = 0, max_sp = 0;
@@ -386,102 +101,8 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
             Hit h;
             n_rays++;
             closest_hit<COUNT>(sc, ray, h, stack, RT_BLOCK, pp.lds_slots, n_box, n_tri, max_sp);
-            if (h.tri == REF_NONE) {
-                color = vmul(color, ambient); finished = true;      // raytrace.cu:220-223
-            } else {
-                if (COUNT) n_shaded++;
-                // ---- triangle_interpolate, raytrace.cu:80-96 ----
-                const float4* sq = reinterpret_cast<const float4*>(sc.shade + h.tri);
-                const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
-                const float u = h.u, v = h.v;
-                const float w = 1.0f - u - v;
-                const v3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-                const v3 normal = vnormalize(vadd(vadd(vscale(n0, w), vscale(n1, u)), vscale(n2, v)));
-                const int mat_id = __float_as_int(s3.w);
-                const float4* mq = reinterpret_cast<const float4*>(sc.mats + mat_id);
-                const float4 m0 = mq[0], m1 = mq[1];
-                const int mtype = __float_as_int(m0.x);
-                const float optical_density = m1.x, metal_fuzz = m1.y;
-                const int mtex = __float_as_int(m1.z);
-                v3 hit_color;
-                if (mtex < 0) {
-                    hit_color = mk3(m0.y, m0.z, m0.w);
-                } else {
-                    const float tcx = w * s2.y + u * s2.w + v * s3.y;
-                    const float tcy = w * s2.z + u * s3.x + v * s3.z;
-                    if (COUNT) n_tex++;
-                    hit_color = tex_fetch(sc, mtex, tcx, tcy);
-                }
-                const v3 rd = mk3(ray.dx, ray.dy, ray.dz);
-                const v3 point = vadd(mk3(ray.ox, ray.oy, ray.oz), vscale(rd, h.t));   // primitives.cuh:17-19
-                const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);         // scatters done so far on this path
-                uint32_t w_rr, w_dec, w2_, w3_;
-                philox((uint32_t)pixel, (uint32_t)sample, bounce * 65536u, 0u, k0, k1, w_rr, w_dec, w2_, w3_);
-                const float decision = u01(w_dec);
-                if (mtype == RT_MAT_LIGHT) {
-                    color = vmul(color, hit_color); finished = true;                 // raytrace.cu:226-229
-                } else if (u01(w_rr) < pp.rr) {                                      // :230
-                    // ---- material_scatter, raytrace.cu:120-195 ----
-                    v3 dir = mk3(0.0f, 0.0f, 0.0f);
-                    bool scattered = true;
-                    const float dn = vdot(rd, normal);
-                    if (mtype == RT_MAT_LAMBERTIAN) {
-                        v3 d0 = normal;
-                        if (dn > 0.0f) d0 = vneg(normal);
-                        dir = vnormalize(vadd(d0, unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k0, k1)));
-                        const float cos_theta = fabsf(vdot(dir, normal));
-                        color = vmul(color, vscale(hit_color, cos_theta));
-                    } else if (mtype == RT_MAT_METAL) {
-                        v3 nn = normal;
-                        if (dn > 0.0f) nn = vneg(normal);
-                        const v3 rnd = unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k0, k1);
-                        if (4.0f * decision < 3.0f + metal_fuzz) {
-                            dir = vadd(nn, rnd);
-                            const float cos_theta = fabsf(vdot(dir, nn));
-                            color = vmul(color, vscale(hit_color, cos_theta));
-                        } else {
-                            dir = vadd(vnormalize(reflect3(rd, nn)), vscale(rnd, metal_fuzz));
-                        }
-                    } else if (mtype == RT_MAT_REFLECTIVE) {
-                        dir = reflect3(rd, normal);
-                        color = vmul(color, hit_color);
-                    } else if (mtype == RT_MAT_REFRACTIVE) {
-                        v3 outward;
-                        float ni_over_nt, cosine;
-                        if (dn > 0.0f) {
-                            outward = vneg(normal);
-                            ni_over_nt = optical_density;
-                            cosine = optical_density * dn;
-                        } else {
-                            outward = normal;
-                            ni_over_nt = 1.0f / optical_density;
-                            cosine = -dn;
-                        }
-                        float reflect_prob = 1.0f;
-                        {   // refract, raytrace.cu:102-110
-                            const float dt = vdot(rd, outward);
-                            const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
-                            if (disc > 0.0f) {
-                                dir = vsub(vscale(vsub(rd, vscale(outward, dt)), ni_over_nt), vscale(outward, sqrtf(disc)));
-                                float r0 = (1.0f - optical_density) / (1.0f + optical_density);   // schlick, :112-116
-                                r0 = r0 * r0;
-                                reflect_prob = r0 + (1.0f - r0) * powi5(1.0f - cosine);
-                            }
-                        }
-                        if (decision < reflect_prob) dir = reflect3(rd, normal);
-                        color = vmul(color, hit_color);
-                    } else {
-                        scattered = false;
-                    }
-                    if (scattered) {
-                        ray_set(ray, vadd(point, vscale(dir, 1e-4f)), dir);         // raytrace.cu:118
-                    } else {
-                        color = vmul(color, ambient); finished = true;             // :232-235
-                    }
-                } else {
-                    color = vmul(color, ambient); finished = true;                 // :238-241
-                }
-            }
+            const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);              // scatters done so far on this path
+            finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
         }
         if (finished) {
             n_paths++;
@@ -534,6 +155,178 @@ __global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int f
         else { carry[3 * (size_t)i] = tx; carry[3 * (size_t)i + 1] = ty; carry[3 * (size_t)i + 2] = tz; }
     }
     out[3 * (size_t)i] = ox; out[3 * (size_t)i + 1] = oy; out[3 * (size_t)i + 2] = oz;
+}
+
+// ---------------------------------------------------------------------------
+// wavefront variant: path state in HBM, one kernel per stage
+// ---------------------------------------------------------------------------
+// The same paths as path_kernel (same addressed draws, same traversal, same slots), scheduled differently:
+// a pool of up to `capacity` paths lives in HBM as three float4 planes; every iteration runs
+//   shade    : consume the hit of every pooled path (miss / light / roulette / scatter), write finished paths'
+//              radiance to their slots and COMPACT the survivors into the other pool with a 64-bit ballot +
+//              lane prefix count + one atomic per wave;
+//   plan     : one thread sizes the refill (free room vs. paths not yet started);
+//   generate : append that many new camera paths, in tile order, so fresh primary rays fill whole waves;
+//   extend   : closest hit for every pooled path.
+// Every stage runs with full waves and few registers; the price is ~200 B of state traffic per segment.
+struct WfPools {
+    float4* p0[2];      // origin.xyz, dir.x
+    float4* p1[2];      // dir.y, dir.z, pixel, sample (bit patterns)
+    float4* p2[2];      // color.rgb, depth left (int bits; < 0 marks a lane outside the image)
+    float4* hit;        // t, u, v, packed triangle (written by extend for the pool it ran on)
+};
+
+struct WfCtl {
+    uint32_t count[2];              // paths in pool 0 / 1
+    uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
+    unsigned long long cursor;      // next path id to start
+    unsigned long long gen_first;   // first path id of the current refill
+};
+
+__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity) {
+    if (threadIdx.x || blockIdx.x) return;
+    const uint32_t have = ctl->count[nxt];
+    const unsigned long long left = total - ctl->cursor;
+    const uint32_t room = capacity - have;
+    const uint32_t n = left < (unsigned long long)room ? (uint32_t)left : room;
+    ctl->gen_base = have;
+    ctl->gen_count = n;
+    ctl->gen_first = ctl->cursor;
+    ctl->cursor += n;
+    ctl->count[nxt] = have + n;
+    ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
+}
+
+// Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
+// tile's next sample, then the next tile, so consecutive waves trace neighbouring primary rays.
+__global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __restrict__ ctl, WfPools pools, int nxt, PathParams pp) {
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    uint32_t n_paths = 0;
+    if (j < ctl->gen_count) {
+        const unsigned long long id = ctl->gen_first + j;
+        const uint32_t per_tile = (uint32_t)pp.n_samples * 256u;
+        const uint32_t tile = (uint32_t)(id / per_tile);
+        const uint32_t rem = (uint32_t)(id - (unsigned long long)tile * per_tile);
+        const uint32_t s = rem >> 8, p = rem & 255u;
+        const int tx = tile % pp.tiles_x, ty = tile / pp.tiles_x;
+        const int wave = p >> 6, lane = p & 63;
+        const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+        const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+        const uint32_t pos = ctl->gen_base + j;
+        const int sample = pp.first_sample + (int)s;
+        int depth = pp.max_depth;
+        v3 dir = mk3(0.0f, 0.0f, 1.0f);
+        int pixel = 0;
+        if (x < pp.cam.width && y < pp.cam.height) {
+            pixel = y * pp.cam.width + x;
+            uint32_t w0, w1, w2, w3;
+            philox((uint32_t)pixel, (uint32_t)(sample / pp.batch), 0u, 1u, pp.key0, pp.key1, w0, w1, w2, w3);
+            dir = primary_dir(pp.cam, x, y, u01(w0), u01(w1));
+            if (depth == 0) {
+                // `while (depth--)` never runs: the path adds nothing (raytrace.cu:213, 243)
+                float* slot = pp.slots + ((size_t)s * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
+                depth = -1;
+                n_paths = 1;
+            }
+        } else {
+            depth = -1;
+        }
+        pools.p0[nxt][pos] = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], dir.x);
+        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(pixel), __int_as_float(sample));
+        pools.p2[nxt][pos] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(depth));
+    }
+    wave_add(pp.counters + RT_CNT_PATHS, n_paths);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const WfCtl* __restrict__ ctl, WfPools pools, int nxt,
+                                                             int lds_slots, unsigned long long* counters) {
+    extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
+    lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    uint32_t n_box = 0, n_tri = 0, n_rays = 0, max_sp = 0;
+    if (i < ctl->count[nxt]) {
+        const float4 a = pools.p0[nxt][i], b = pools.p1[nxt][i];
+        const int depth = __float_as_int(pools.p2[nxt][i].w);
+        Hit h;
+        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+        if (depth > 0) {
+            RayD r;
+            ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+            n_rays = 1;
+            closest_hit<COUNT>(sc, r, h, stack, RT_BLOCK, lds_slots, n_box, n_tri, max_sp);
+        }
+        pools.hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+    }
+    wave_add(counters + RT_CNT_RAYS, n_rays);
+    if (COUNT) {
+        wave_add(counters + RT_CNT_BOX_TESTS, n_box);
+        wave_add(counters + RT_CNT_TRI_TESTS, n_tri);
+        atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const int nxt = cur ^ 1;
+    uint32_t n_shaded = 0, n_tex = 0, n_paths = 0;
+    bool survives = false;
+    float4 o0, o1, o2;
+    if (i < ctl->count[cur]) {
+        const float4 a = pools.p0[cur][i], b = pools.p1[cur][i], c = pools.p2[cur][i], hq = pools.hit[i];
+        int depth = __float_as_int(c.w);
+        if (depth > 0) {
+            const int pixel = __float_as_int(b.z), sample = __float_as_int(b.w);
+            depth--;                                                 // the segment extend just traced (raytrace.cu:213)
+            ShadeConst sk;
+            sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
+            sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
+            RayD ray;
+            ray.ox = a.x; ray.oy = a.y; ray.oz = a.z; ray.dx = a.w; ray.dy = b.x; ray.dz = b.y;
+            ray.ix = ray.iy = ray.iz = 0.0f;                         // shading never reads the inverses
+            Hit h;
+            h.t = hq.x; h.u = hq.y; h.v = hq.z; h.tri = __float_as_uint(hq.w);
+            v3 color = mk3(c.x, c.y, c.z);
+            const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);
+            bool finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
+            if (!finished && depth == 0) {
+                // the next `while (depth--)` test fails: out of depth, the path adds nothing (raytrace.cu:243)
+                finished = true;
+                color = mk3(0.0f, 0.0f, 0.0f);
+            }
+            if (finished) {
+                n_paths = 1;
+                float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
+            } else {
+                survives = true;
+                o0 = make_float4(ray.ox, ray.oy, ray.oz, ray.dx);
+                o1 = make_float4(ray.dy, ray.dz, b.z, b.w);
+                o2 = make_float4(color.x, color.y, color.z, __int_as_float(depth));
+            }
+        }
+    }
+    // queue compaction: 64-bit ballot, prefix count of the lanes below, one atomic per wave
+    const unsigned long long mask = __ballot(survives);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == (int)(__ffsll((long long)mask) - 1)) base = atomicAdd(&ctl->count[nxt], (uint32_t)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+        if (survives) {
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            pools.p0[nxt][pos] = o0;
+            pools.p1[nxt][pos] = o1;
+            pools.p2[nxt][pos] = o2;
+        }
+    }
+    wave_add(pp.counters + RT_CNT_PATHS, n_paths);
+    if (COUNT) {
+        wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
+        wave_add(pp.counters + RT_CNT_TEX_FETCHES, n_tex);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -619,6 +412,12 @@ struct rt_context {
     int opt_lds_slots = 12;          // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 256;              // samples per pixel held in the slot buffer at once
+    int opt_mode = 0;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
+    int opt_wf_log2 = 22;            // wavefront pool capacity = 2^this paths
+    WfPools pools{};
+    WfCtl* d_ctl = nullptr;
+    WfCtl* h_ctl = nullptr;          // pinned
+    uint32_t pool_capacity = 0;
     float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
     int stack_slots = 1;
@@ -629,6 +428,21 @@ static void free_scene(rt_context* c) {
     void** ptrs[] = {&c->d_nodes, &c->d_isect, &c->d_shade, &c->d_origin, &c->d_mats, &c->d_tex, &c->d_texels};
     for (void** p : ptrs) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
     c->have_scene = false;
+}
+
+static void free_pools(rt_context* c) {
+    for (int k = 0; k < 2; k++) {
+        if (c->pools.p0[k]) (void)hipFree(c->pools.p0[k]);
+        if (c->pools.p1[k]) (void)hipFree(c->pools.p1[k]);
+        if (c->pools.p2[k]) (void)hipFree(c->pools.p2[k]);
+        c->pools.p0[k] = c->pools.p1[k] = c->pools.p2[k] = nullptr;
+    }
+    if (c->pools.hit) (void)hipFree(c->pools.hit);
+    c->pools.hit = nullptr;
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    c->d_ctl = nullptr; c->h_ctl = nullptr;
+    c->pool_capacity = 0;
 }
 
 template <class T>
@@ -682,6 +496,7 @@ int rt_destroy(rt_context* ctx) {
     free_scene(ctx);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    free_pools(ctx);
     delete ctx;
     return RT_OK;
 }
@@ -691,6 +506,12 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     switch (option) {
     case RT_OPT_COUNTERS: ctx->opt_counters = value ? 1 : 0; return RT_OK;
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
+    case RT_OPT_MODE:
+        if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
+        ctx->opt_mode = value; return RT_OK;
+    case RT_OPT_WF_CAPACITY_LOG2:
+        if (value < 8 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^8..2^28 paths");
+        ctx->opt_wf_log2 = value; return RT_OK;
     case RT_OPT_LDS_SLOTS:
         if (value < 1 || value > 32) return fail(RT_ERR_INVALID, "rt_set_option: LDS stack slots must be 1..32");
         ctx->opt_lds_slots = value; return RT_OK;
@@ -800,6 +621,54 @@ static int lds_slots(const rt_context* ctx) { return ctx->stack_slots < ctx->opt
 static size_t stack_bytes(const rt_context* ctx) { return (size_t)lds_slots(ctx) * RT_BLOCK * sizeof(uint2); }
 static bool stack_fits(const rt_context* ctx) { return ctx->stack_slots <= lds_slots(ctx) + RT_SPILL_SLOTS; }
 
+// One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.
+static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
+    const uint32_t cap = 1u << ctx->opt_wf_log2;
+    if (ctx->pool_capacity != cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        free_pools(ctx);
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc((void**)&ctx->pools.p0[k], (size_t)cap * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&ctx->pools.p1[k], (size_t)cap * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&ctx->pools.p2[k], (size_t)cap * sizeof(float4)));
+        }
+        HIP_TRY(hipMalloc((void**)&ctx->pools.hit, (size_t)cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&ctx->d_ctl, sizeof(WfCtl)));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_ctl, sizeof(WfCtl), hipHostMallocDefault));
+        ctx->pool_capacity = cap;
+    }
+    const unsigned long long total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
+    HIP_TRY(hipMemsetAsync(ctx->d_ctl, 0, sizeof(WfCtl), s));
+    const dim3 grid(cap / RT_BLOCK), block(RT_BLOCK);
+    const int slots_lds = lds_slots(ctx);
+    int cur = 0;
+    for (unsigned iter = 0;; iter++) {
+        const int nxt = cur ^ 1;
+        if (iter > 0) {
+            if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
+            else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
+        }
+        hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
+        hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
+        if (ctx->opt_counters)
+            hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, stack_bytes(ctx), s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, ctx->d_counters);
+        else
+            hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, stack_bytes(ctx), s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, ctx->d_counters);
+        HIP_TRY(hipGetLastError());
+        cur = nxt;
+        // the host does not know the pool's population: look at it every few iterations
+        if ((iter & 7u) == 7u) {
+            HIP_TRY(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->h_ctl->cursor >= total && ctx->h_ctl->count[cur] == 0) break;
+        }
+        if (iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
+    }
+    return RT_OK;
+}
+
 int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
                 float russian_roulette, float* d_output, void* stream) {
     if (!ctx || !ambient || !d_output) return fail(RT_ERR_INVALID, "rt_raytrace: null argument");
@@ -844,10 +713,14 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
         pp.n_chunks = (pp.n_samples + pp.chunk - 1) / pp.chunk;
         const long long nblocks = (long long)pp.tiles_x * pp.tiles_y * pp.n_chunks;
         if (nblocks > 0x7FFFFFFFLL) return fail(RT_ERR_INVALID, "rt_raytrace: grid too large");
-        if (ctx->opt_counters)
+        if (ctx->opt_mode == 1) {
+            const int rc = wavefront_pass(ctx, pp, s);
+            if (rc) return rc;
+        } else if (ctx->opt_counters) {
             hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
-        else
+        } else {
             hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+        }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixel + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, n_pixel, pp.first_sample,
                            pp.n_samples, semantic_batch, done + pass >= spp ? 1 : 0, (const float*)ctx->d_slots,

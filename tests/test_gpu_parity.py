@@ -167,6 +167,49 @@ def test_radiance_sums_and_counters_bit_exact(gpu_ctx, name, kw, spp, batch):
     assert gcnt[capi.CNT_PATHS] == p.cfg.width * p.cfg.height * spp
 
 
+@pytest.mark.parametrize("name,kw,spp,batch,cap", [
+    ("material_box", dict(width=64, height=40, n_samples=16), 16, 4, 10),      # pool of 1024 paths: many refills and compactions
+    ("material_box", dict(width=33, height=17, n_samples=10), 10, 4, 8),       # partial tiles (lanes outside the image), pool of 256
+    ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 8, 8, 14),
+    ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 4, 22),   # pool larger than the job
+    ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 2, 12),
+])
+def test_wavefront_variant_bit_exact(gpu_ctx, name, kw, spp, batch, cap):
+    """The wavefront schedule (state in HBM, stage kernels, ballot compaction) traces the same paths: same image, same counts."""
+    p = Pair(gpu_ctx, getattr(scene, name)(**kw))
+    ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, batch), 0, spp)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, cap)
+    try:
+        got, gcnt = p.gpu_render(0, spp, batch)
+        # twice in a row on the same context: the control block and pools are reused
+        again, _ = p.gpu_render(0, spp, batch)
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 22)
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert same_f32(again, ref)
+    assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2]
+    assert gcnt[capi.CNT_SHADED] == rcnt[3] and gcnt[capi.CNT_TEX_FETCHES] == rcnt[4]
+    assert gcnt[capi.CNT_PATHS] == p.cfg.width * p.cfg.height * spp
+
+
+def test_wavefront_depth_zero_and_glass(gpu_ctx):
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    try:
+        asm = scene.material_box(width=32, height=32, n_samples=4)
+        asm.config.max_depth = 0
+        p = Pair(gpu_ctx, asm)
+        got, cnt = p.gpu_render(0, 4, 4)
+        assert not got.any() and cnt[capi.CNT_RAYS] == 0 and cnt[capi.CNT_PATHS] == 32 * 32 * 4
+        p = Pair(gpu_ctx, scene.formula1(width=96, height=60, n_samples=8, detail=0.05, glass=True))
+        ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, 4), 0, 8)
+        got, gcnt = p.gpu_render(0, 8, 4)
+        assert same_f32(got, ref) and gcnt[capi.CNT_RAYS] == rcnt[0]
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+
+
 def test_glass_variant_bit_exact(gpu_ctx):
     # every car triangle refractive: long specular chains, the divergence stress case
     p = Pair(gpu_ctx, scene.formula1(width=96, height=60, n_samples=8, detail=0.05, glass=True))
