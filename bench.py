@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--lds-slots", type=int, default=0, help="traversal stack levels in LDS (0 = library default)")
     ap.add_argument("--mode", default="", choices=["", "megakernel", "wavefront"], help="path-state design (default: library default)")
     ap.add_argument("--wf-log2", type=int, default=0, help="wavefront pool capacity, log2 paths (0 = library default)")
+    ap.add_argument("--wf-run", type=int, default=0)
+    ap.add_argument("--wf-burst", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -103,6 +105,10 @@ def main():
         ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT if args.mode == "wavefront" else capi.MODE_MEGAKERNEL)
     if args.wf_log2:
         ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, args.wf_log2)
+    if args.wf_run:
+        ctx.set_option(capi.OPT_WF_RUN, args.wf_run)
+    if args.wf_burst:
+        ctx.set_option(capi.OPT_WF_BURST, args.wf_burst)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height
@@ -144,7 +150,13 @@ def main():
     mix = {"box_tests_per_ray": c[capi.CNT_BOX_TESTS] / rays_i, "tri_tests_per_ray": c[capi.CNT_TRI_TESTS] / rays_i,
            "shaded_per_ray": c[capi.CNT_SHADED] / rays_i, "tex_per_ray": c[capi.CNT_TEX_FETCHES] / rays_i,
            "rays_per_path": c[capi.CNT_RAYS] / max(1, c[capi.CNT_PATHS]), "max_stack": c[capi.CNT_MAX_STACK],
-           "stack_slots_needed": stats["stack_slots"]}
+           "stack_slots_needed": stats["stack_slots"],
+           # lanes doing useful work per executed trip of the inner-node loop (1.0 = all 64 lanes busy)
+           "node_loop_lane_util": (c[capi.CNT_BOX_TESTS] / 2) / max(1, 64 * c[capi.CNT_WAVE_NODE_TRIPS]),
+           # triangle tests per executed leaf phase and lane (2.0 = every lane tests a full leaf every time)
+           "leaf_phase_tests_per_lane": c[capi.CNT_TRI_TESTS] / max(1, 64 * c[capi.CNT_WAVE_LEAF_TRIPS]),
+           "wave_node_trips_per_ray": c[capi.CNT_WAVE_NODE_TRIPS] * 64 / rays_i,
+           "wave_leaf_trips_per_ray": c[capi.CNT_WAVE_LEAF_TRIPS] * 64 / rays_i}
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
     ctx.set_option(capi.OPT_COUNTERS, 0)
 

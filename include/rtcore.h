@@ -103,7 +103,9 @@ enum {
     RT_CNT_TEX_FETCHES,       /* bilinear texture fetches */
     RT_CNT_PATHS,             /* camera samples finished */
     RT_CNT_MAX_STACK,         /* deepest traversal stack seen (only with RT_OPT_COUNTERS) */
-    RT_CNT_COUNT = 8
+    RT_CNT_WAVE_NODE_TRIPS,   /* inner-node loop trips executed per wave, summed (RT_OPT_COUNTERS): with BOX_TESTS/2 gives lane utilisation */
+    RT_CNT_WAVE_LEAF_TRIPS,   /* leaf-phase trips executed per wave, summed (RT_OPT_COUNTERS) */
+    RT_CNT_COUNT = 16
 };
 
 /* options for rt_set_option */
@@ -113,11 +115,13 @@ enum {
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
     RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 256);
                                  scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
-    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 12); deeper levels spill to private memory */
-    RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths (default); 1 = wavefront: path state in HBM,
+    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 8); deeper levels spill to private memory */
+    RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
                                  In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
-    RT_OPT_WF_CAPACITY_LOG2 = 7 /* wavefront pool size = 2^value paths (default 22; 7 * 16 bytes of HBM per path) */
+    RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = 2^value paths (default 24; 7 * 16 bytes of HBM per path) */
+    RT_OPT_WF_RUN = 8,        /* wavefront: pool entries one extend workgroup drains (default 1024); scheduling only */
+    RT_OPT_WF_BURST = 9       /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
 };
 
 const char* rt_last_error(void);

@@ -160,21 +160,37 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 // children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
 #define RT_SPILL_SLOTS 56
 typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
+
+struct TravCounters {
+    uint32_t n_box, n_tri, max_sp, w_node, w_leaf;
+};
+
+// The walk, one step at a time, so that kernels can interleave it with other work (refilling idle lanes).
+// State: `cur` = node or leaf to visit next (REF_NONE = walk over), `sp` = stack height.
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
-                                            uint32_t& n_box, uint32_t& n_tri, uint32_t& max_sp) {
-    h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+struct Walker {
+    uint32_t cur;
+    int sp;
+    lds_uint2* stack;
+    int stride, lds_slots;
     uint2 spill[RT_SPILL_SLOTS];
-    int sp = 0;
-    uint32_t cur = REF_NONE;
-    {
+
+    __device__ __forceinline__ void init(lds_uint2* stack_, int stride_, int lds_slots_) {
+        stack = stack_; stride = stride_; lds_slots = lds_slots_; cur = REF_NONE; sp = 0;
+    }
+
+    __device__ __forceinline__ void begin(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) {
+        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+        sp = 0;
+        cur = REF_NONE;
         float tn;
-        if (COUNT) n_box++;
+        if (COUNT) tc.n_box++;
         if (slab(sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0], sc.root.bmax[1], sc.root.bmax[2], r, tn))
             cur = sc.root.ref;
     }
+
     // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
-    auto pop = [&]() -> uint32_t {
+    __device__ __forceinline__ uint32_t pop(const Hit& h) {
         while (sp > 0) {
             --sp;
             uint2 e;
@@ -183,40 +199,66 @@ __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, H
             if (!(__uint_as_float(e.y) > h.t)) return e.x;
         }
         return REF_NONE;
-    };
-    for (;;) {
-        // inner nodes: one 64-byte record decides both children.  REF_NONE has the leaf bit set and ends the loop.
-        while (!(cur & REF_LEAF)) {
-            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-            const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-            float tnl, tnr;
-            if (COUNT) n_box += 2;
-            const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
-            const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
-            const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
-            // upstream pushes left then right, so the right child is visited first.  A left child whose
-            // t_near already exceeds the best t can be dropped now: the best t only shrinks.
-            if (hr) {
-                if (hl) {
-                    const uint2 e = make_uint2(refl, __float_as_uint(tnl));
-                    if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
-                    else spill[sp - lds_slots] = e;
-                    sp++;
-                    if (COUNT) max_sp = max(max_sp, (uint32_t)sp);
-                }
-                cur = refr;
-            } else if (hl) {
-                cur = refl;
-            } else {
-                cur = pop();
-            }
+    }
+
+    __device__ __forceinline__ bool at_inner() const { return !(cur & REF_LEAF); }        // REF_NONE has the leaf bit set
+    __device__ __forceinline__ bool at_leaf() const { return cur != REF_NONE && (cur & REF_LEAF); }
+    __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
+
+    // visit the inner node `cur`: one 64-byte record decides both children
+    __device__ __forceinline__ void node_step(const SceneDev& sc, const RayD& r, const Hit& h, TravCounters& tc) {
+        const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+        float tnl, tnr;
+        if (COUNT) {
+            tc.n_box += 2;
+            // one lane per wave counts the trip: sum over lanes = trips the wave executed
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }
-        if (cur == REF_NONE) break;
+        const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
+        const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
+        const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
+        // upstream pushes left then right, so the right child is visited first.  A left child whose
+        // t_near already exceeds the best t can be dropped now: the best t only shrinks.
+        if (hr) {
+            if (hl) {
+                const uint2 e = make_uint2(refl, __float_as_uint(tnl));
+                if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
+                else spill[sp - lds_slots] = e;
+                sp++;
+                if (COUNT) tc.max_sp = max(tc.max_sp, (uint32_t)sp);
+            }
+            cur = refr;
+        } else if (hl) {
+            cur = refl;
+        } else {
+            cur = pop(h);
+        }
+    }
+
+    // visit the leaf `cur`: left triangle, then right (raytrace.cu:57-62)
+    __device__ __forceinline__ void leaf_step(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) {
         const uint32_t p = cur & REF_MASK;
-        if (COUNT) n_tri += (cur & REF_PAIR) ? 2u : 1u;
+        if (COUNT) {
+            tc.n_tri += (cur & REF_PAIR) ? 2u : 1u;
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_leaf++;
+        }
         tri_test(sc.isect, p, r, h);
         if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
-        cur = pop();
+        cur = pop(h);
+    }
+};
+
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
+                                            TravCounters& tc) {
+    Walker<COUNT> w;
+    w.init(stack, stride, lds_slots);
+    w.begin(sc, r, h, tc);
+    for (;;) {
+        while (w.at_inner()) w.node_step(sc, r, h, tc);
+        if (w.done()) break;
+        w.leaf_step(sc, r, h, tc);
     }
 }
 

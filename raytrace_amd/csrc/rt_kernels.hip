@@ -29,6 +29,14 @@
 
 #include "rt_device.h"
 
+__device__ __forceinline__ void add_trav_counters(unsigned long long* counters, const TravCounters& tc) {
+    wave_add(counters + RT_CNT_BOX_TESTS, tc.n_box);
+    wave_add(counters + RT_CNT_TRI_TESTS, tc.n_tri);
+    atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)tc.max_sp);
+    wave_add(counters + RT_CNT_WAVE_NODE_TRIPS, tc.w_node);
+    wave_add(counters + RT_CNT_WAVE_LEAF_TRIPS, tc.w_leaf);
+}
+
 // ---------------------------------------------------------------------------
 // the path kernel
 // ---------------------------------------------------------------------------
@@ -61,7 +69,8 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     sk.rr = pp.rr; sk.k0 = k0; sk.k1 = k1;
     const v3 cam_pos = mk3(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2]);
 
-    uint32_t n_rays = 0, n_box = 0, n_tri = 0, n_shaded = 0, n_tex = 0, n_paths = 0, max_sp = 0;
+    uint32_t n_rays = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
+    TravCounters tc = {0, 0, 0, 0, 0};
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
             depth--;
             Hit h;
             n_rays++;
-            closest_hit<COUNT>(sc, ray, h, stack, RT_BLOCK, pp.lds_slots, n_box, n_tri, max_sp);
+            closest_hit<COUNT>(sc, ray, h, stack, RT_BLOCK, pp.lds_slots, tc);
             const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);              // scatters done so far on this path
             finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
         }
@@ -120,11 +129,9 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     wave_add(pp.counters + RT_CNT_RAYS, n_rays);
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
     if (COUNT) {
-        wave_add(pp.counters + RT_CNT_BOX_TESTS, n_box);
-        wave_add(pp.counters + RT_CNT_TRI_TESTS, n_tri);
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
         wave_add(pp.counters + RT_CNT_TEX_FETCHES, n_tex);
-        atomicMax(pp.counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
+        add_trav_counters(pp.counters, tc);
     }
 }
 
@@ -239,32 +246,74 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
 
+// Closest hit for every pooled path.  Traversal lengths differ wildly between the rays of a wave, so a lane does
+// not own one ray: each workgroup owns a run of `rays_per_block` pool entries and every lane that finishes a
+// ray stores its hit and claims the next entry of the run (64-bit ballot of the idle lanes, one LDS atomic per
+// wave, lane prefix count), until the run is drained.  The inner-node loop runs at most `node_burst` trips
+// before the wave looks at leaves and idle lanes again.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const WfCtl* __restrict__ ctl, WfPools pools, int nxt,
-                                                             int lds_slots, unsigned long long* counters) {
+                                                             int lds_slots, uint32_t rays_per_block, int node_burst,
+                                                             unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    uint32_t n_box = 0, n_tri = 0, n_rays = 0, max_sp = 0;
-    if (i < ctl->count[nxt]) {
-        const float4 a = pools.p0[nxt][i], b = pools.p1[nxt][i];
-        const int depth = __float_as_int(pools.p2[nxt][i].w);
+    // the run cursor sits behind the stacks, inside the one dynamic LDS block
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* run_next = (lds_u32*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK);
+    const uint32_t count = ctl->count[nxt];
+    const uint32_t run_begin = blockIdx.x * rays_per_block;
+    const uint32_t run_end = min(count, run_begin + rays_per_block);
+    uint32_t n_rays = 0;
+    TravCounters tc = {0, 0, 0, 0, 0};
+    if (run_begin < count) {                       // uniform for the workgroup
+        if (threadIdx.x == 0) *run_next = run_begin;
+        __syncthreads();
+        const int lane = threadIdx.x & 63;
+        Walker<COUNT> w;
+        w.init(stack, RT_BLOCK, lds_slots);
+        RayD r;
+        ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
         Hit h;
         h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-        if (depth > 0) {
-            RayD r;
-            ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-            n_rays = 1;
-            closest_hit<COUNT>(sc, r, h, stack, RT_BLOCK, lds_slots, n_box, n_tri, max_sp);
+        int ridx = -1;                             // pool entry this lane is tracing, -1 = none
+        for (;;) {
+            const bool idle = w.done();
+            if (idle && ridx >= 0) {
+                pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                ridx = -1;
+            }
+            const unsigned long long m = __ballot(idle);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd((uint32_t*)run_next, (uint32_t)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (idle) {
+                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (idx < run_end) {
+                        const float4 a = pools.p0[nxt][idx], b = pools.p1[nxt][idx];
+                        const int depth = __float_as_int(pools.p2[nxt][idx].w);
+                        ridx = (int)idx;
+                        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+                        if (depth > 0) {           // lanes outside the image carry depth < 0: their hit stays "none"
+                            ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+                            n_rays++;
+                            w.begin(sc, r, h, tc);
+                        }
+                    }
+                }
+            }
+            if (!__any(ridx >= 0)) break;
+            int burst = node_burst;
+            while (w.at_inner()) {
+                w.node_step(sc, r, h, tc);
+                if (--burst == 0) break;
+            }
+            if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
         }
-        pools.hit[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
     }
     wave_add(counters + RT_CNT_RAYS, n_rays);
-    if (COUNT) {
-        wave_add(counters + RT_CNT_BOX_TESTS, n_box);
-        wave_add(counters + RT_CNT_TRI_TESTS, n_tri);
-        atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
-    }
+    if (COUNT) add_trav_counters(counters, tc);
 }
 
 template <bool COUNT>
@@ -338,14 +387,15 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    uint32_t n_box = 0, n_tri = 0, n_r = 0, max_sp = 0;
+    uint32_t n_r = 0;
+    TravCounters tc = {0, 0, 0, 0, 0};
     if (i < n_rays) {
         RayD r;
         ray_set(r, mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]),
                 mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]));
         Hit h;
         n_r = 1;
-        closest_hit<true>(sc, r, h, stack, RT_BLOCK, lds_slots, n_box, n_tri, max_sp);
+        closest_hit<true>(sc, r, h, stack, RT_BLOCK, lds_slots, tc);
         int o = -1, ti = -1;
         if (h.tri != REF_NONE) { const TriOrigin og = sc.origin[h.tri]; o = og.object; ti = og.triangle; }
         obj[i] = o; tri[i] = ti; t[i] = h.t;
@@ -353,9 +403,7 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
         if (v) v[i] = h.v;
     }
     wave_add(counters + RT_CNT_RAYS, n_r);
-    wave_add(counters + RT_CNT_BOX_TESTS, n_box);
-    wave_add(counters + RT_CNT_TRI_TESTS, n_tri);
-    atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)max_sp);
+    add_trav_counters(counters, tc);
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void primary_rays_kernel(CameraFrame cam, uint32_t key0, uint32_t key1, uint32_t batch_index,
@@ -409,11 +457,13 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
-    int opt_lds_slots = 12;          // stack levels kept in LDS (deeper ones spill to private memory)
+    int opt_lds_slots = 8;           // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 256;              // samples per pixel held in the slot buffer at once
-    int opt_mode = 0;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
-    int opt_wf_log2 = 22;            // wavefront pool capacity = 2^this paths
+    int opt_mode = 1;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
+    int opt_wf_log2 = 24;            // wavefront pool capacity = 2^this paths
+    int opt_wf_run = 1024;           // pool entries one extend workgroup drains
+    int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
     WfCtl* d_ctl = nullptr;
     WfCtl* h_ctl = nullptr;          // pinned
@@ -512,6 +562,12 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_WF_CAPACITY_LOG2:
         if (value < 8 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^8..2^28 paths");
         ctx->opt_wf_log2 = value; return RT_OK;
+    case RT_OPT_WF_RUN:
+        if (value < 256 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: extend run must be 256..2^20 entries");
+        ctx->opt_wf_run = value; return RT_OK;
+    case RT_OPT_WF_BURST:
+        if (value < 1 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: node burst must be >= 1");
+        ctx->opt_wf_burst = value; return RT_OK;
     case RT_OPT_LDS_SLOTS:
         if (value < 1 || value > 32) return fail(RT_ERR_INVALID, "rt_set_option: LDS stack slots must be 1..32");
         ctx->opt_lds_slots = value; return RT_OK;
@@ -650,12 +706,14 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         }
         hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
+        const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
+        const dim3 egrid((cap + rpb - 1) / rpb);
         if (ctx->opt_counters)
-            hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, stack_bytes(ctx), s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
         else
-            hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, stack_bytes(ctx), s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
         HIP_TRY(hipGetLastError());
         cur = nxt;
         // the host does not know the pool's population: look at it every few iterations

@@ -19,5 +19,8 @@ def gpu_ctx():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from raytrace_amd import capi
     ctx = capi.Context(0)
+    # the shared context runs the megakernel unless a test switches it; wavefront tests pick small pools
+    ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+    ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
     yield ctx
     ctx.close()
