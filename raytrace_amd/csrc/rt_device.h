@@ -15,7 +15,7 @@ using namespace rtc;
 // ---------------------------------------------------------------------------
 struct SceneDev {
     ChildRec root;            // box + reference of the whole scene (root of the object-level tree)
-    const Node64* nodes;
+    const Node4* nodes;
     const TriIsect* isect;
     const TriShade* shade;
     const TriOrigin* origin;
@@ -155,6 +155,7 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 // Closest hit over the whole scene in upstream's visiting order (cuda/raytrace.cu:44-78, 214-219):
 // right child first, leaf left triangle then right, prune on t_near > best t when a node comes off the
 // stack.  The objects hang under the object-level tree, so there is one walk, not one per object.
+// The walk runs on the two-level nodes (rt_packed.h, Node4).
 // `stack` points at this lane's column of the LDS stack; consecutive slots are `stride` entries apart.
 // The first `lds_slots` stack levels live in LDS; deeper levels (rare: a level is only used while BOTH
 // children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
@@ -205,35 +206,39 @@ struct Walker {
     __device__ __forceinline__ bool at_leaf() const { return cur != REF_NONE && (cur & REF_LEAF); }
     __device__ __forceinline__ bool done() const { return cur == REF_NONE; }
 
-    // visit the inner node `cur`: one 64-byte record decides both children
+    __device__ __forceinline__ void push(uint32_t ref, float tn, TravCounters& tc) {
+        const uint2 e = make_uint2(ref, __float_as_uint(tn));
+        if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
+        else spill[sp - lds_slots] = e;
+        sp++;
+        if (COUNT) tc.max_sp = max(tc.max_sp, (uint32_t)sp);
+    }
+
+    // visit the two-level node `cur`: one 128-byte record decides up to four grandchildren, slot 0 = visited first
     __device__ __forceinline__ void node_step(const SceneDev& sc, const RayD& r, const Hit& h, TravCounters& tc) {
         const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-        float tnl, tnr;
+        const float4 a0 = q[0], b0 = q[1], a1 = q[2], b1 = q[3], a2 = q[4], b2 = q[5], a3 = q[6], b3 = q[7];
+        const uint32_t r0 = __float_as_uint(b0.z), r1 = __float_as_uint(b1.z), r2 = __float_as_uint(b2.z), r3 = __float_as_uint(b3.z);
         if (COUNT) {
-            tc.n_box += 2;
+            tc.n_box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }
-        const bool hl = slab(a.x, a.y, a.z, a.w, b.x, b.y, r, tnl) && !(tnl > h.t);
-        const bool hr = slab(c.x, c.y, c.z, c.w, d.x, d.y, r, tnr) && !(tnr > h.t);
-        const uint32_t refl = __float_as_uint(b.z), refr = __float_as_uint(d.z);
-        // upstream pushes left then right, so the right child is visited first.  A left child whose
-        // t_near already exceeds the best t can be dropped now: the best t only shrinks.
-        if (hr) {
-            if (hl) {
-                const uint2 e = make_uint2(refl, __float_as_uint(tnl));
-                if (sp < lds_slots) { stack[sp * stride].x = e.x; stack[sp * stride].y = e.y; }
-                else spill[sp - lds_slots] = e;
-                sp++;
-                if (COUNT) tc.max_sp = max(tc.max_sp, (uint32_t)sp);
-            }
-            cur = refr;
-        } else if (hl) {
-            cur = refl;
-        } else {
-            cur = pop(h);
-        }
+        float t0, t1, t2, t3;
+        const bool h0 = (r0 != REF_NONE) && slab(a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, r, t0) && !(t0 > h.t);
+        const bool h1 = (r1 != REF_NONE) && slab(a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, r, t1) && !(t1 > h.t);
+        const bool h2 = (r2 != REF_NONE) && slab(a2.x, a2.y, a2.z, a2.w, b2.x, b2.y, r, t2) && !(t2 > h.t);
+        const bool h3 = (r3 != REF_NONE) && slab(a3.x, a3.y, a3.z, a3.w, b3.x, b3.y, r, t3) && !(t3 > h.t);
+        // The first hit slot is visited now; later hit slots wait on the stack, last slot deepest.  A slot whose
+        // t_near already exceeds the best t is dropped now: the best t only shrinks (upstream would drop it at pop time).
+        if (h3 && (h0 || h1 || h2)) push(r3, t3, tc);
+        if (h2 && (h0 || h1)) push(r2, t2, tc);
+        if (h1 && h0) push(r1, t1, tc);
+        if (h0) cur = r0;
+        else if (h1) cur = r1;
+        else if (h2) cur = r2;
+        else if (h3) cur = r3;
+        else cur = pop(h);
     }
 
     // visit the leaf `cur`: left triangle, then right (raytrace.cu:57-62)

@@ -256,6 +256,44 @@ static ChildRec build_top(PackedScene& ps, int first, int last, int depth, int& 
     return r;
 }
 
+// Collapse the binary node `bref` and its two children into one Node4; returns its index.
+// `need` = stack entries a walk below this node can have pending at once.
+static uint32_t collapse(PackedScene& ps, uint32_t bref, int& need) {
+    const Node64& b = ps.nodes[bref];
+    ChildRec slots[4];
+    int used = 0;
+    const ChildRec order[2] = {b.c[1], b.c[0]};          // right child is visited first
+    for (const ChildRec& x : order) {
+        if (x.ref & REF_LEAF) {
+            slots[used++] = x;
+        } else {
+            slots[used++] = ps.nodes[x.ref].c[1];
+            slots[used++] = ps.nodes[x.ref].c[0];
+        }
+    }
+    const uint32_t me = (uint32_t)ps.nodes4.size();
+    ps.nodes4.emplace_back();
+    need = 0;
+    for (int i = 0; i < used; i++) {
+        int below = 0;
+        if (!(slots[i].ref & REF_LEAF)) slots[i].ref = collapse(ps, slots[i].ref, below);
+        // while the walk is below slot i, the later slots of this node may all be waiting on the stack
+        const int pending = (used - 1 - i) + below;
+        if (pending > need) need = pending;
+    }
+    Node4& out = ps.nodes4[me];
+    for (int i = 0; i < 4; i++) {
+        if (i < used) {
+            out.c[i] = slots[i];
+        } else {
+            for (int a = 0; a < 3; a++) { out.c[i].bmin[a] = INFINITY; out.c[i].bmax[a] = -INFINITY; }
+            out.c[i].ref = REF_NONE;
+            out.c[i].aux = 0;
+        }
+    }
+    return me;
+}
+
 int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
     ps = PackedScene();
     size_t total_tris = 0;
@@ -300,7 +338,13 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
     // its t_near never exceeds a member's (the slab arithmetic is monotone in the bounds).
     int top_depth = 0;
     ps.root = build_top(ps, 0, n_objects, 0, top_depth);
-    ps.max_depth += top_depth;
+    ps.max_depth = 0;
+    if (!(ps.root.ref & REF_LEAF)) {
+        int need = 0;
+        ps.nodes4.reserve(ps.nodes.size() / 2 + 16);
+        ps.root.ref = collapse(ps, ps.root.ref, need);
+        ps.max_depth = need;
+    }
     return 0;
 }
 

@@ -21,7 +21,8 @@ struct CameraFrame {          // what cuda/camera.cu:49-59 passes to its kernel
 struct PackedScene {
     std::vector<ChildRec> top;       // one per upstream object, in object order
     ChildRec root;                   // the whole scene: root of the object-level tree
-    std::vector<Node64> nodes;
+    std::vector<Node64> nodes;       // binary nodes (intermediate; not uploaded)
+    std::vector<Node4> nodes4;       // two-level nodes the kernels walk; root.ref indexes this array
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
     std::vector<TriOrigin> origin;

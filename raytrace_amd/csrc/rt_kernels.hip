@@ -627,7 +627,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     free_scene(ctx);
     uint64_t bytes = 0;
     int rc;
-    if ((rc = upload_vec(ps.nodes, &ctx->d_nodes, bytes))) return rc;
+    if ((rc = upload_vec(ps.nodes4, &ctx->d_nodes, bytes))) return rc;
     if ((rc = upload_vec(ps.isect, &ctx->d_isect, bytes))) return rc;
     if ((rc = upload_vec(ps.shade, &ctx->d_shade, bytes))) return rc;
     if ((rc = upload_vec(ps.origin, &ctx->d_origin, bytes))) return rc;
@@ -635,7 +635,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     if ((rc = upload_vec(tex, &ctx->d_tex, bytes))) return rc;
     if ((rc = upload_vec(texels, &ctx->d_texels, bytes))) return rc;
     ctx->dev.root = ps.root;
-    ctx->dev.nodes = (const Node64*)ctx->d_nodes;
+    ctx->dev.nodes = (const Node4*)ctx->d_nodes;
     ctx->dev.isect = (const TriIsect*)ctx->d_isect;
     ctx->dev.shade = (const TriShade*)ctx->d_shade;
     ctx->dev.origin = (const TriOrigin*)ctx->d_origin;
@@ -645,7 +645,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->dev.n_materials = n_materials;
     ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
     ctx->stats[0] = ps.isect.size();
-    ctx->stats[1] = ps.nodes.size();
+    ctx->stats[1] = ps.nodes4.size();
     ctx->stats[2] = (uint64_t)ctx->stack_slots;
     ctx->stats[3] = bytes;
     ctx->stats[4] = (uint64_t)n_objects;
