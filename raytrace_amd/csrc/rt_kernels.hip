@@ -263,7 +263,6 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const 
     const uint32_t count = ctl->count[nxt];
     const uint32_t run_begin = blockIdx.x * rays_per_block;
     const uint32_t run_end = min(count, run_begin + rays_per_block);
-    uint32_t n_rays = 0;
     TravCounters tc = {0, 0, 0, 0, 0};
     if (run_begin < count) {                       // uniform for the workgroup
         if (threadIdx.x == 0) *run_next = run_begin;
@@ -297,7 +296,6 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const 
                         h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
                         if (depth > 0) {           // lanes outside the image carry depth < 0: their hit stays "none"
                             ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-                            n_rays++;
                             w.begin(sc, r, h, tc);
                         }
                     }
@@ -312,15 +310,21 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const 
             if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
         }
     }
-    wave_add(counters + RT_CNT_RAYS, n_rays);
     if (COUNT) add_trav_counters(counters, tc);
 }
 
+// Workgroups of 1024 lanes: the survivors of all 16 waves are numbered through LDS and the workgroup takes its
+// range of the next pool with ONE returning atomic -- a returning atomic on a single word sustains only ~90 per
+// microsecond chip-wide, so one per wave (262k per iteration of a 16M-path pool) would cost more than the shading.
+#define RT_SHADE_BLOCK 1024
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
+    __shared__ uint32_t wave_survivors[RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t wave_finished[RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
     const int nxt = cur ^ 1;
-    uint32_t n_shaded = 0, n_tex = 0, n_paths = 0;
+    uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0;
     bool survives = false;
     float4 o0, o1, o2;
     if (i < ctl->count[cur]) {
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* 
         if (depth > 0) {
             const int pixel = __float_as_int(b.z), sample = __float_as_int(b.w);
             depth--;                                                 // the segment extend just traced (raytrace.cu:213)
+            n_rays = 1;
             ShadeConst sk;
             sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
             sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
@@ -357,21 +362,36 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* 
             }
         }
     }
-    // queue compaction: 64-bit ballot, prefix count of the lanes below, one atomic per wave
+    // queue compaction: 64-bit ballot per wave, wave totals through LDS, one atomic per workgroup, lane prefix count
     const unsigned long long mask = __ballot(survives);
-    if (mask) {
-        const int lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == (int)(__ffsll((long long)mask) - 1)) base = atomicAdd(&ctl->count[nxt], (uint32_t)__popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-        if (survives) {
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            pools.p0[nxt][pos] = o0;
-            pools.p1[nxt][pos] = o1;
-            pools.p2[nxt][pos] = o2;
-        }
+    const unsigned long long done = __ballot(n_paths != 0);
+    const unsigned long long traced = __ballot(n_rays != 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        wave_survivors[wave] = (uint32_t)__popcll(mask);
+        wave_finished[wave] = (uint32_t)__popcll(done) | ((uint32_t)__popcll(traced) << 16);   // both <= 64
     }
-    wave_add(pp.counters + RT_CNT_PATHS, n_paths);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0, fin = 0, rays = 0;
+        for (int k = 0; k < RT_SHADE_BLOCK / 64; k++) {
+            total += wave_survivors[k];
+            fin += wave_finished[k] & 0xFFFFu;
+            rays += wave_finished[k] >> 16;
+        }
+        block_base = total ? atomicAdd(&ctl->count[nxt], total) : 0u;
+        if (fin) atomicAdd(pp.counters + RT_CNT_PATHS, (unsigned long long)fin);
+        if (rays) atomicAdd(pp.counters + RT_CNT_RAYS, (unsigned long long)rays);   // one closest-hit query was traced per live path
+    }
+    __syncthreads();
+    if (survives) {
+        uint32_t pos = block_base;
+        for (int k = 0; k < wave; k++) pos += wave_survivors[k];
+        pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        pools.p0[nxt][pos] = o0;
+        pools.p1[nxt][pos] = o1;
+        pools.p2[nxt][pos] = o2;
+    }
     if (COUNT) {
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
         wave_add(pp.counters + RT_CNT_TEX_FETCHES, n_tex);
@@ -560,7 +580,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
     case RT_OPT_WF_CAPACITY_LOG2:
-        if (value < 8 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^8..2^28 paths");
+        if (value < 10 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^10..2^28 paths");
         ctx->opt_wf_log2 = value; return RT_OK;
     case RT_OPT_WF_RUN:
         if (value < 256 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: extend run must be 256..2^20 entries");
@@ -701,8 +721,9 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     for (unsigned iter = 0;; iter++) {
         const int nxt = cur ^ 1;
         if (iter > 0) {
-            if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
-            else hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
+            const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
+            if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
+            else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
         }
         hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);

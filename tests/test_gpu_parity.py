@@ -169,8 +169,8 @@ def test_radiance_sums_and_counters_bit_exact(gpu_ctx, name, kw, spp, batch):
 
 
 @pytest.mark.parametrize("name,kw,spp,batch,cap", [
-    ("material_box", dict(width=64, height=40, n_samples=16), 16, 4, 10),      # pool of 1024 paths: many refills and compactions
-    ("material_box", dict(width=33, height=17, n_samples=10), 10, 4, 8),       # partial tiles (lanes outside the image), pool of 256
+    ("material_box", dict(width=64, height=40, n_samples=16), 16, 4, 11),      # pool of 2048 paths: many refills and compactions
+    ("material_box", dict(width=33, height=17, n_samples=10), 10, 4, 10),      # partial tiles (lanes outside the image), pool of 1024
     ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 8, 8, 14),
     ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 4, 22),   # pool larger than the job
     ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 2, 12),
