@@ -11,9 +11,12 @@ one process per GPU) the scene is replicated, every rank traces its own sample r
 inside the timed region.  Rank 0 prints ONE JSON line.
 
 value      = whole-job Mrays/s: closest-hit queries (device counter) of all ranks / max-over-ranks time.
-roofline   = algorithmic bytes per launch / mean kernel time (HIP events on the launch stream), against 8 TB/s HBM.
-             bytes per ray = 32*box_tests + 36*triangle_tests + 100*shaded + 16*texture_fetches, measured per
-             ray by an instrumented pass of the same kernel, plus 24 B per pixel per launch for the buffer.
+roofline   = the dominant kernel (wavefront: wf_extend_kernel, the closest-hit walk; megakernel: path_kernel):
+             algorithmic bytes per launch / mean launch time, against 8 TB/s HBM.  Launch times come from HIP
+             events the library records on the launch stream around every launch of that kernel in the timed
+             region (rt_get_timing).  Bytes per ray = 32*box_tests + 36*triangle_tests for the walk (+ 100*shaded
+             + 16*texture_fetches when the kernel also shades), per-ray counts measured by an instrumented pass
+             of the same kernels on the same workload.
 cpu_baseline = the CPU oracle (a port of upstream's logic, OpenMP) on a bounded sample of the same
              workload, rank 0, N = 1 only.
 """
@@ -151,12 +154,15 @@ def main():
            "shaded_per_ray": c[capi.CNT_SHADED] / rays_i, "tex_per_ray": c[capi.CNT_TEX_FETCHES] / rays_i,
            "rays_per_path": c[capi.CNT_RAYS] / max(1, c[capi.CNT_PATHS]), "max_stack": c[capi.CNT_MAX_STACK],
            "stack_slots_needed": stats["stack_slots"],
-           # lanes doing useful work per executed trip of the inner-node loop (1.0 = all 64 lanes busy)
-           "node_loop_lane_util": (c[capi.CNT_BOX_TESTS] / 2) / max(1, 64 * c[capi.CNT_WAVE_NODE_TRIPS]),
+           "node_visits_per_ray": c[capi.CNT_NODE_VISITS] / rays_i,
+           # lanes doing useful work per executed trip of the node loop (1.0 = all 64 lanes busy)
+           "node_loop_lane_util": c[capi.CNT_NODE_VISITS] / max(1, 64 * c[capi.CNT_WAVE_NODE_TRIPS]),
            # triangle tests per executed leaf phase and lane (2.0 = every lane tests a full leaf every time)
            "leaf_phase_tests_per_lane": c[capi.CNT_TRI_TESTS] / max(1, 64 * c[capi.CNT_WAVE_LEAF_TRIPS]),
+           "boxes_per_node_visit": 0.0,
            "wave_node_trips_per_ray": c[capi.CNT_WAVE_NODE_TRIPS] * 64 / rays_i,
            "wave_leaf_trips_per_ray": c[capi.CNT_WAVE_LEAF_TRIPS] * 64 / rays_i}
+    mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
     ctx.set_option(capi.OPT_COUNTERS, 0)
 
@@ -164,6 +170,7 @@ def main():
     for s in range(args.warmup):
         run_step(s)
     torch.cuda.synchronize()
+    ctx.set_option(capi.OPT_TIMING, 1)
     ctx.reset_counters()
 
     # ---- timed region ----
@@ -180,9 +187,10 @@ def main():
     elapsed = time.perf_counter() - t0
 
     cnt = ctx.counters()
+    tim = ctx.timing()
     rays = float(cnt[capi.CNT_RAYS])
     paths = float(cnt[capi.CNT_PATHS])
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    step_ms = [a.elapsed_time(b) for a, b in events]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,26 +202,48 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         mrays = rays / elapsed / 1e6
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
-        rays_per_launch = float(cnt[capi.CNT_RAYS]) / max(1, args.steps)
-        algo_bytes = rays_per_launch * bytes_per_ray + 24.0 * npix
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        my_rays = float(cnt[capi.CNT_RAYS])
+        if tim["extend_launches"]:
+            kname, k_ms_total, k_launches = "wf_extend_kernel", tim["extend_ms"], tim["extend_launches"]
+            k_bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"]
+        else:
+            kname, k_ms_total, k_launches = "path_kernel", tim["path_ms"], tim["path_launches"]
+            k_bytes_per_ray = bytes_per_ray
+        k_ms = k_ms_total / max(1, k_launches)
+        algo_bytes_per_launch = my_rays * k_bytes_per_ray / max(1, k_launches)
+        achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # every 16-byte piece a lane loads is one access of the CU's vector L1, which serves about one per clock
+        l1_accesses_per_ray = 8.0 * mix["box_tests_per_ray"] / max(1e-9, mix["boxes_per_node_visit"]) + 3.0 * mix["tri_tests_per_ray"] + 4.0
         out = {
             "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (procedural stand-in for the formula-1 OBJ, which upstream does not ship)",
-            "config": {"workload": f"scene_{args.scene} textured, {cfg.width}x{cfg.height}, depth {cfg.max_depth}, rr {cfg.russian_roulette}, "
+            "config": {"workload": f"scene_{args.scene}, {cfg.width}x{cfg.height}, depth {cfg.max_depth}, rr {cfg.russian_roulette}, "
                                    f"{FRAME_SPP}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
                        "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
+                       "mode": args.mode or "library default (wavefront)",
                        "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU"},
             "seconds_per_frame": round(ms_per_step * 1e-3 * FRAME_SPP / (spp * world), 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
-            "kernel_ms_mean": round(k_ms, 3),
+            "gpu_ms_per_step_events": round(float(np.mean(step_ms)), 3) if step_ms else None,
             "work_mix": {k: round(v, 4) for k, v in mix.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "bytes_per_ray": round(bytes_per_ray, 1), "kernel": "path_kernel"},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": kname, "kernel_ms_mean": round(k_ms, 4), "launches": int(k_launches),
+                         "bytes_per_ray": round(k_bytes_per_ray, 1), "rays_per_launch": round(my_rays / max(1, k_launches), 1)},
+            "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "shade_ms": round(tim["shade_ms"], 2),
+                             "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},
+            "l1_access_bound": {"accesses_per_ray": round(l1_accesses_per_ray, 1),
+                                "achieved_G_per_s": round(my_rays * l1_accesses_per_ray / max(1e-9, k_ms_total * 1e-3) / 1e9, 1),
+                                "peak_G_per_s": 256 * 2.4, "note": "one 16-byte lane access per clock per CU (tools/microbench/gather.hip)"},
             "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -105,6 +105,7 @@ enum {
     RT_CNT_MAX_STACK,         /* deepest traversal stack seen (only with RT_OPT_COUNTERS) */
     RT_CNT_WAVE_NODE_TRIPS,   /* inner-node loop trips executed per wave, summed (RT_OPT_COUNTERS): with BOX_TESTS/2 gives lane utilisation */
     RT_CNT_WAVE_LEAF_TRIPS,   /* leaf-phase trips executed per wave, summed (RT_OPT_COUNTERS) */
+    RT_CNT_NODE_VISITS,       /* two-level nodes fetched, summed over lanes (RT_OPT_COUNTERS) */
     RT_CNT_COUNT = 16
 };
 
@@ -119,8 +120,9 @@ enum {
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
                                  In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
-    RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = 2^value paths (default 24; 7 * 16 bytes of HBM per path) */
+    RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = 2^value paths (default 25; 7 * 16 bytes of HBM per path) */
     RT_OPT_WF_RUN = 8,        /* wavefront: pool entries one extend workgroup drains (default 1024); scheduling only */
+    RT_OPT_TIMING = 11,       /* 1 = bracket every traversal kernel launch with HIP events on the launch stream (see rt_get_timing) */
     RT_OPT_WF_BURST = 9       /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
 };
 
@@ -193,7 +195,12 @@ int rt_closest_hit(rt_context* ctx, int n_rays, const float* d_rays, int32_t* d_
                    int32_t* d_triangle, float* d_t, float* d_u, float* d_v, void* stream);
 
 int rt_get_counters(rt_context* ctx, uint64_t out[RT_CNT_COUNT]);   /* synchronises the device */
-int rt_reset_counters(rt_context* ctx);
+int rt_reset_counters(rt_context* ctx);                             /* also clears the timing totals */
+
+/* With RT_OPT_TIMING: out[0],[1] = total milliseconds and launches of the wavefront closest-hit kernel (wf_extend),
+ * out[2],[3] = of the wavefront shading kernel, out[4],[5] = of the megakernel (path_kernel), since the last
+ * rt_reset_counters.  Measured with HIP events on the stream the kernels were launched on.  Synchronises the device. */
+int rt_get_timing(rt_context* ctx, double out[8]);
 
 /* Scene statistics after upload: out[0]=triangles, [1]=packed inner nodes, [2]=max stack depth,
  * [3]=device bytes of the packed scene, [4]=objects. */

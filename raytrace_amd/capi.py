@@ -31,9 +31,10 @@ MATERIAL_DTYPE = np.dtype(
 
 MAT_NONE, MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_REFRACTIVE, MAT_REFLECTIVE = range(6)
 
-CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK, CNT_WAVE_NODE_TRIPS, CNT_WAVE_LEAF_TRIPS = range(9)
+CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK, CNT_WAVE_NODE_TRIPS, CNT_WAVE_LEAF_TRIPS, CNT_NODE_VISITS = range(10)
 CNT_COUNT = 16
 OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS, OPT_MODE, OPT_WF_CAPACITY_LOG2, OPT_WF_RUN, OPT_WF_BURST = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_TIMING = 11
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 
 
@@ -52,7 +53,7 @@ class RtTransform(C.Structure):
 EXPORTS = [
     "rt_last_error", "rt_abi_version", "rt_build_bvh", "rt_apply_transform", "rt_create", "rt_destroy", "rt_set_option",
     "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_post_process", "rt_primary_rays",
-    "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_scene_stats", "rt_device_alloc", "rt_device_free",
+    "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_device_alloc", "rt_device_free",
     "rt_device_zero", "rt_copy_to_host", "rt_copy_to_device", "rt_synchronize",
 ]
 
@@ -95,6 +96,7 @@ def load():
         "rt_closest_hit": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
         "rt_get_counters": [vp, C.POINTER(u64)],
         "rt_reset_counters": [vp],
+        "rt_get_timing": [vp, C.POINTER(C.c_double)],
         "rt_scene_stats": [vp, C.POINTER(u64)],
         "rt_device_alloc": [vp, u64, C.POINTER(vp)],
         "rt_device_free": [vp, vp],
@@ -208,6 +210,12 @@ class Context:
         out = (C.c_uint64 * CNT_COUNT)()
         check(self.lib.rt_get_counters(self.h, out))
         return list(out)
+
+    def timing(self):
+        out = (C.c_double * 8)()
+        check(self.lib.rt_get_timing(self.h, out))
+        return {"extend_ms": out[0], "extend_launches": int(out[1]), "shade_ms": out[2], "shade_launches": int(out[3]),
+                "path_ms": out[4], "path_launches": int(out[5])}
 
     def reset_counters(self):
         check(self.lib.rt_reset_counters(self.h))

@@ -163,7 +163,7 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
 
 struct TravCounters {
-    uint32_t n_box, n_tri, max_sp, w_node, w_leaf;
+    uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node;
 };
 
 // The walk, one step at a time, so that kernels can interleave it with other work (refilling idle lanes).
@@ -221,6 +221,7 @@ struct Walker {
         const uint32_t r0 = __float_as_uint(b0.z), r1 = __float_as_uint(b1.z), r2 = __float_as_uint(b2.z), r3 = __float_as_uint(b3.z);
         if (COUNT) {
             tc.n_box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+            tc.n_node++;
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }

@@ -35,6 +35,7 @@ __device__ __forceinline__ void add_trav_counters(unsigned long long* counters, 
     atomicMax(counters + RT_CNT_MAX_STACK, (unsigned long long)tc.max_sp);
     wave_add(counters + RT_CNT_WAVE_NODE_TRIPS, tc.w_node);
     wave_add(counters + RT_CNT_WAVE_LEAF_TRIPS, tc.w_leaf);
+    wave_add(counters + RT_CNT_NODE_VISITS, tc.n_node);
 }
 
 // ---------------------------------------------------------------------------
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     const v3 cam_pos = mk3(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2]);
 
     uint32_t n_rays = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
-    TravCounters tc = {0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0, 0, 0, 0, 0};
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const 
     const uint32_t count = ctl->count[nxt];
     const uint32_t run_begin = blockIdx.x * rays_per_block;
     const uint32_t run_end = min(count, run_begin + rays_per_block);
-    TravCounters tc = {0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0, 0, 0, 0, 0};
     if (run_begin < count) {                       // uniform for the workgroup
         if (threadIdx.x == 0) *run_next = run_begin;
         __syncthreads();
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     uint32_t n_r = 0;
-    TravCounters tc = {0, 0, 0, 0, 0};
+    TravCounters tc = {0, 0, 0, 0, 0, 0};
     if (i < n_rays) {
         RayD r;
         ray_set(r, mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]),
@@ -480,8 +481,14 @@ struct rt_context {
     int opt_lds_slots = 8;           // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 256;              // samples per pixel held in the slot buffer at once
+    int opt_timing = 0;              // record HIP events around the traversal kernels
+    std::vector<hipEvent_t> ev_pool; // event pairs: [2k] before, [2k+1] after
+    std::vector<int> ev_kind;        // per pair: 0 = wf_extend, 1 = wf_shade, 2 = path_kernel
+    size_t ev_used = 0;              // pairs recorded since the last collection
+    double time_ms[3] = {0, 0, 0};
+    uint64_t time_launches[3] = {0, 0, 0};
     int opt_mode = 1;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
-    int opt_wf_log2 = 24;            // wavefront pool capacity = 2^this paths
+    int opt_wf_log2 = 25;            // wavefront pool capacity = 2^this paths
     int opt_wf_run = 1024;           // pool entries one extend workgroup drains
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
@@ -567,6 +574,7 @@ int rt_destroy(rt_context* ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     free_pools(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
     return RT_OK;
 }
@@ -576,6 +584,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     switch (option) {
     case RT_OPT_COUNTERS: ctx->opt_counters = value ? 1 : 0; return RT_OK;
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
+    case RT_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
@@ -697,6 +706,35 @@ static int lds_slots(const rt_context* ctx) { return ctx->stack_slots < ctx->opt
 static size_t stack_bytes(const rt_context* ctx) { return (size_t)lds_slots(ctx) * RT_BLOCK * sizeof(uint2); }
 static bool stack_fits(const rt_context* ctx) { return ctx->stack_slots <= lds_slots(ctx) + RT_SPILL_SLOTS; }
 
+// --- optional per-kernel timing with HIP events on the launch stream ---
+static int timing_begin(rt_context* ctx, int kind, hipStream_t s) {
+    if (!ctx->opt_timing) return -1;
+    if (ctx->ev_used * 2 + 2 > ctx->ev_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        ctx->ev_pool.push_back(a); ctx->ev_pool.push_back(b);
+        ctx->ev_kind.push_back(kind);
+    }
+    const int k = (int)ctx->ev_used++;
+    ctx->ev_kind[k] = kind;
+    (void)hipEventRecord(ctx->ev_pool[2 * k], s);
+    return k;
+}
+static void timing_end(rt_context* ctx, int k, hipStream_t s) {
+    if (k >= 0) (void)hipEventRecord(ctx->ev_pool[2 * k + 1], s);
+}
+// Fold the recorded pairs into the totals; the caller has synchronised the stream.
+static void timing_collect(rt_context* ctx) {
+    for (size_t k = 0; k < ctx->ev_used; k++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[2 * k], ctx->ev_pool[2 * k + 1]) == hipSuccess) {
+            ctx->time_ms[ctx->ev_kind[k]] += ms;
+            ctx->time_launches[ctx->ev_kind[k]]++;
+        }
+    }
+    ctx->ev_used = 0;
+}
+
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.
 static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const uint32_t cap = 1u << ctx->opt_wf_log2;
@@ -722,25 +760,30 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         const int nxt = cur ^ 1;
         if (iter > 0) {
             const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
+            const int tk = timing_begin(ctx, 1, s);
             if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
             else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
+            timing_end(ctx, tk, s);
         }
         hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
         const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
         const dim3 egrid((cap + rpb - 1) / rpb);
+        const int tke = timing_begin(ctx, 0, s);
         if (ctx->opt_counters)
             hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
                                slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
         else
             hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
                                slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
+        timing_end(ctx, tke, s);
         HIP_TRY(hipGetLastError());
         cur = nxt;
         // the host does not know the pool's population: look at it every few iterations
         if ((iter & 7u) == 7u) {
             HIP_TRY(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            timing_collect(ctx);
             if (ctx->h_ctl->cursor >= total && ctx->h_ctl->count[cur] == 0) break;
         }
         if (iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
@@ -795,10 +838,11 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
         if (ctx->opt_mode == 1) {
             const int rc = wavefront_pass(ctx, pp, s);
             if (rc) return rc;
-        } else if (ctx->opt_counters) {
-            hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
         } else {
-            hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+            const int tk = timing_begin(ctx, 2, s);
+            if (ctx->opt_counters) hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+            else hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+            timing_end(ctx, tk, s);
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixel + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, n_pixel, pp.first_sample,
@@ -852,11 +896,23 @@ int rt_get_counters(rt_context* ctx, uint64_t out[RT_CNT_COUNT]) {
     return RT_OK;
 }
 
+int rt_get_timing(rt_context* ctx, double out[8]) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_timing: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    timing_collect(ctx);
+    for (int k = 0; k < 3; k++) { out[2 * k] = ctx->time_ms[k]; out[2 * k + 1] = (double)ctx->time_launches[k]; }
+    out[6] = out[7] = 0.0;
+    return RT_OK;
+}
+
 int rt_reset_counters(rt_context* ctx) {
     if (!ctx) return fail(RT_ERR_INVALID, "rt_reset_counters: null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(ctx->d_counters, 0, RT_CNT_COUNT * sizeof(uint64_t)));
+    timing_collect(ctx);
+    for (int k = 0; k < 3; k++) { ctx->time_ms[k] = 0.0; ctx->time_launches[k] = 0; }
     return RT_OK;
 }
 
