@@ -77,10 +77,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the reduce goes through host memory); the measured runs use nccl (= RCCL).
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    stat_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- scene (replicated on every rank) ----
     t0 = time.time()
@@ -95,7 +103,7 @@ def main():
     cfg = asm.config
     objs = scene.finalize(asm)
     t_build = time.time() - t0
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device_index)
     ctx.upload_scene(objs, asm.materials, asm.textures)
     stats = ctx.scene_stats()
     if args.chunk:
@@ -137,8 +145,11 @@ def main():
         if ev:
             ev[1].record()
         if world > 1:
-            staging.copy_(accum)
-            reduce_to_root(staging, 0)
+            if backend == "nccl":
+                staging.copy_(accum)
+                reduce_to_root(staging, 0)
+            else:
+                reduce_to_root(accum.cpu(), 0)
 
     # ---- instrumented pass: per-ray work mix of this kernel on this workload (not timed) ----
     ctx.set_option(capi.OPT_COUNTERS, 1)
@@ -192,10 +203,10 @@ def main():
     paths = float(cnt[capi.CNT_PATHS])
     step_ms = [a.elapsed_time(b) for a, b in events]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays, paths], dtype=torch.float64, device="cuda")
+        r = torch.tensor([rays, paths], dtype=torch.float64, device=stat_device)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays, paths = float(r[0].item()), float(r[1].item())
 

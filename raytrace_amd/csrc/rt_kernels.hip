@@ -493,7 +493,8 @@ struct rt_context {
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
     WfCtl* d_ctl = nullptr;
-    WfCtl* h_ctl = nullptr;          // pinned
+    WfCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots
+    hipEvent_t ctl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t pool_capacity = 0;
     float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
@@ -518,6 +519,7 @@ static void free_pools(rt_context* c) {
     c->pools.hit = nullptr;
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    for (auto& e : c->ctl_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     c->d_ctl = nullptr; c->h_ctl = nullptr;
     c->pool_capacity = 0;
 }
@@ -735,6 +737,8 @@ static void timing_collect(rt_context* ctx) {
     ctx->ev_used = 0;
 }
 
+#define RT_CTL_RING 4
+#define RT_CTL_GROUP 4
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.
 static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const uint32_t cap = 1u << ctx->opt_wf_log2;
@@ -748,7 +752,8 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         }
         HIP_TRY(hipMalloc((void**)&ctx->pools.hit, (size_t)cap * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&ctx->d_ctl, sizeof(WfCtl)));
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_ctl, sizeof(WfCtl), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_ctl, RT_CTL_RING * sizeof(WfCtl), hipHostMallocDefault));
+        for (int k = 0; k < RT_CTL_RING; k++) HIP_TRY(hipEventCreateWithFlags(&ctx->ctl_ev[k], hipEventDisableTiming));
         ctx->pool_capacity = cap;
     }
     const unsigned long long total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
@@ -756,6 +761,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const dim3 grid(cap / RT_BLOCK), block(RT_BLOCK);
     const int slots_lds = lds_slots(ctx);
     int cur = 0;
+    int snap_cur[RT_CTL_RING] = {0, 0, 0, 0};
     for (unsigned iter = 0;; iter++) {
         const int nxt = cur ^ 1;
         if (iter > 0) {
@@ -779,12 +785,19 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         timing_end(ctx, tke, s);
         HIP_TRY(hipGetLastError());
         cur = nxt;
-        // the host does not know the pool's population: look at it every few iterations
-        if ((iter & 7u) == 7u) {
-            HIP_TRY(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            timing_collect(ctx);
-            if (ctx->h_ctl->cursor >= total && ctx->h_ctl->count[cur] == 0) break;
+        // The host does not know the pool's population.  After every group of iterations it queues a snapshot
+        // of the control block, and it reads the snapshot of the group BEFORE, so the stream always holds
+        // a group of work while the host waits; the price is one group of empty launches at the very end.
+        if ((iter % RT_CTL_GROUP) == RT_CTL_GROUP - 1) {
+            const unsigned g = iter / RT_CTL_GROUP;
+            HIP_TRY(hipMemcpyAsync(&ctx->h_ctl[g % RT_CTL_RING], ctx->d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(ctx->ctl_ev[g % RT_CTL_RING], s));
+            snap_cur[g % RT_CTL_RING] = cur;
+            if (g > 0) {
+                const unsigned q = (g - 1) % RT_CTL_RING;
+                HIP_TRY(hipEventSynchronize(ctx->ctl_ev[q]));
+                if (ctx->h_ctl[q].cursor >= total && ctx->h_ctl[q].count[snap_cur[q]] == 0) break;
+            }
         }
         if (iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
     }
