@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--wf-log2", type=int, default=0, help="wavefront pool capacity, log2 paths (0 = library default)")
     ap.add_argument("--wf-run", type=int, default=0)
     ap.add_argument("--wf-burst", type=int, default=0)
+    ap.add_argument("--hot-nodes", type=int, default=-1)
     args = ap.parse_args()
 
     import torch
@@ -120,6 +121,8 @@ def main():
         ctx.set_option(capi.OPT_WF_RUN, args.wf_run)
     if args.wf_burst:
         ctx.set_option(capi.OPT_WF_BURST, args.wf_burst)
+    if args.hot_nodes >= 0:
+        ctx.set_option(capi.OPT_HOT_NODES, args.hot_nodes)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height
@@ -173,6 +176,7 @@ def main():
            "boxes_per_node_visit": 0.0,
            "wave_node_trips_per_ray": c[capi.CNT_WAVE_NODE_TRIPS] * 64 / rays_i,
            "wave_leaf_trips_per_ray": c[capi.CNT_WAVE_LEAF_TRIPS] * 64 / rays_i}
+    mix["node_visits_from_lds"] = round(c[capi.CNT_HOT_VISITS] / max(1, c[capi.CNT_NODE_VISITS]), 4)
     mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
     ctx.set_option(capi.OPT_COUNTERS, 0)
@@ -245,7 +249,7 @@ def main():
             "seconds_per_frame": round(ms_per_step * 1e-3 * FRAME_SPP / (spp * world), 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "gpu_ms_per_step_events": round(float(np.mean(step_ms)), 3) if step_ms else None,
-            "work_mix": {k: round(v, 4) for k, v in mix.items()},
+            "work_mix": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mix.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": kname, "kernel_ms_mean": round(k_ms, 4), "launches": int(k_launches),

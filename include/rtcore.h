@@ -106,6 +106,7 @@ enum {
     RT_CNT_WAVE_NODE_TRIPS,   /* inner-node loop trips executed per wave, summed (RT_OPT_COUNTERS): with BOX_TESTS/2 gives lane utilisation */
     RT_CNT_WAVE_LEAF_TRIPS,   /* leaf-phase trips executed per wave, summed (RT_OPT_COUNTERS) */
     RT_CNT_NODE_VISITS,       /* two-level nodes fetched, summed over lanes (RT_OPT_COUNTERS) */
+    RT_CNT_HOT_VISITS,        /* of those, the ones served from the workgroup's LDS copy (RT_OPT_HOT_NODES) */
     RT_CNT_COUNT = 16
 };
 
@@ -123,6 +124,7 @@ enum {
     RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = 2^value paths (default 25; 7 * 16 bytes of HBM per path) */
     RT_OPT_WF_RUN = 8,        /* wavefront: pool entries one extend workgroup drains (default 1024); scheduling only */
     RT_OPT_TIMING = 11,       /* 1 = bracket every traversal kernel launch with HIP events on the launch stream (see rt_get_timing) */
+    RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 64, 0..512) */
     RT_OPT_WF_BURST = 9       /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
 };
 

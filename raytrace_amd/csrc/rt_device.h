@@ -161,9 +161,15 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 // children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
 #define RT_SPILL_SLOTS 56
 typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4v lds_float4;   // native vector type: HIP's float4 class cannot be assigned across address spaces
+__device__ __forceinline__ float4 ld_lds4(const lds_float4* p) { const f4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+// LDS copies of hot nodes sit 144 bytes apart (128 + 16): consecutive nodes start 4 banks further on, so lanes that
+// read the same 16-byte piece of different nodes spread over the banks instead of all landing on one bank group.
+#define RT_HOT_STRIDE 144
 
 struct TravCounters {
-    uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node;
+    uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node, n_hot_visit;
 };
 
 // The walk, one step at a time, so that kernels can interleave it with other work (refilling idle lanes).
@@ -174,11 +180,18 @@ struct Walker {
     int sp;
     lds_uint2* stack;
     int stride, lds_slots;
+    lds_float4* hot;
+    uint32_t n_hot;
     uint2 spill[RT_SPILL_SLOTS];
 
     __device__ __forceinline__ void init(lds_uint2* stack_, int stride_, int lds_slots_) {
         stack = stack_; stride = stride_; lds_slots = lds_slots_; cur = REF_NONE; sp = 0;
+        hot = nullptr; n_hot = 0;
     }
+
+    // The first `n_hot_` node records (breadth-first numbering: the ones nearest to the root, which take more than
+    // half of all visits) have been copied to LDS at `hot_`, RT_HOT_STRIDE bytes apart.
+    __device__ __forceinline__ void set_hot(lds_float4* hot_, uint32_t n_hot_) { hot = hot_; n_hot = n_hot_; }
 
     __device__ __forceinline__ void begin(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) {
         h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
@@ -216,12 +229,20 @@ struct Walker {
 
     // visit the two-level node `cur`: one 128-byte record decides up to four grandchildren, slot 0 = visited first
     __device__ __forceinline__ void node_step(const SceneDev& sc, const RayD& r, const Hit& h, TravCounters& tc) {
-        const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
-        const float4 a0 = q[0], b0 = q[1], a1 = q[2], b1 = q[3], a2 = q[4], b2 = q[5], a3 = q[6], b3 = q[7];
+        float4 a0, b0, a1, b1, a2, b2, a3, b3;
+        if (cur < n_hot) {
+            const lds_float4* q = hot + cur * (RT_HOT_STRIDE / 16);
+            a0 = ld_lds4(q); b0 = ld_lds4(q + 1); a1 = ld_lds4(q + 2); b1 = ld_lds4(q + 3);
+            a2 = ld_lds4(q + 4); b2 = ld_lds4(q + 5); a3 = ld_lds4(q + 6); b3 = ld_lds4(q + 7);
+        } else {
+            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+            a0 = q[0]; b0 = q[1]; a1 = q[2]; b1 = q[3]; a2 = q[4]; b2 = q[5]; a3 = q[6]; b3 = q[7];
+        }
         const uint32_t r0 = __float_as_uint(b0.z), r1 = __float_as_uint(b1.z), r2 = __float_as_uint(b2.z), r3 = __float_as_uint(b3.z);
         if (COUNT) {
             tc.n_box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
             tc.n_node++;
+            tc.n_hot_visit += cur < n_hot;
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }

@@ -294,6 +294,37 @@ static uint32_t collapse(PackedScene& ps, uint32_t bref, int& need) {
     return me;
 }
 
+// Renumber the two-level nodes breadth first from the root: every walk starts at the root, so the nodes nearest
+// to it are by far the most visited, and after this pass they are the first records of the array (kernels can
+// keep a prefix of it close to the lanes).  Visiting order and results do not depend on node numbers.
+static void renumber_breadth_first(PackedScene& ps) {
+    const size_t n = ps.nodes4.size();
+    std::vector<uint32_t> order;            // order[new] = old
+    order.reserve(n);
+    std::vector<uint32_t> renum(n, 0xFFFFFFFFu);
+    order.push_back(ps.root.ref);
+    renum[ps.root.ref] = 0;
+    for (size_t head = 0; head < order.size(); head++) {
+        const Node4& nd = ps.nodes4[order[head]];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = nd.c[k].ref;
+            if (r == REF_NONE || (r & REF_LEAF)) continue;
+            renum[r] = (uint32_t)order.size();
+            order.push_back(r);
+        }
+    }
+    std::vector<Node4> out(order.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        out[i] = ps.nodes4[order[i]];
+        for (int k = 0; k < 4; k++) {
+            uint32_t& r = out[i].c[k].ref;
+            if (r != REF_NONE && !(r & REF_LEAF)) r = renum[r];
+        }
+    }
+    ps.nodes4.swap(out);
+    ps.root.ref = 0;
+}
+
 int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
     ps = PackedScene();
     size_t total_tris = 0;
@@ -344,6 +375,7 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
         ps.nodes4.reserve(ps.nodes.size() / 2 + 16);
         ps.root.ref = collapse(ps, ps.root.ref, need);
         ps.max_depth = need;
+        renumber_breadth_first(ps);
     }
     return 0;
 }

@@ -36,6 +36,7 @@ __device__ __forceinline__ void add_trav_counters(unsigned long long* counters, 
     wave_add(counters + RT_CNT_WAVE_NODE_TRIPS, tc.w_node);
     wave_add(counters + RT_CNT_WAVE_LEAF_TRIPS, tc.w_leaf);
     wave_add(counters + RT_CNT_NODE_VISITS, tc.n_node);
+    wave_add(counters + RT_CNT_HOT_VISITS, tc.n_hot_visit);
 }
 
 // ---------------------------------------------------------------------------
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     const v3 cam_pos = mk3(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2]);
 
     uint32_t n_rays = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
-    TravCounters tc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {};
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -254,23 +255,32 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 // before the wave looks at leaves and idle lanes again.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const WfCtl* __restrict__ ctl, WfPools pools, int nxt,
-                                                             int lds_slots, uint32_t rays_per_block, int node_burst,
+                                                             int lds_slots, uint32_t rays_per_block, int node_burst, uint32_t n_hot,
                                                              unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     // the run cursor sits behind the stacks, inside the one dynamic LDS block
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* run_next = (lds_u32*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK);
+    // behind the cursor: LDS copies of the first n_hot node records
+    lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK + 2);
     const uint32_t count = ctl->count[nxt];
     const uint32_t run_begin = blockIdx.x * rays_per_block;
     const uint32_t run_end = min(count, run_begin + rays_per_block);
-    TravCounters tc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {};
     if (run_begin < count) {                       // uniform for the workgroup
         if (threadIdx.x == 0) *run_next = run_begin;
+        for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += RT_BLOCK)
+        {
+            const float4 v = reinterpret_cast<const float4*>(sc.nodes)[k];
+            f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+            hot[(k >> 3) * (RT_HOT_STRIDE / 16) + (k & 7u)] = o;
+        }
         __syncthreads();
         const int lane = threadIdx.x & 63;
         Walker<COUNT> w;
         w.init(stack, RT_BLOCK, lds_slots);
+        w.set_hot(hot, n_hot);
         RayD r;
         ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
         Hit h;
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     const int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     uint32_t n_r = 0;
-    TravCounters tc = {0, 0, 0, 0, 0, 0};
+    TravCounters tc = {};
     if (i < n_rays) {
         RayD r;
         ray_set(r, mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]),
@@ -490,6 +500,7 @@ struct rt_context {
     int opt_mode = 1;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
     int opt_wf_log2 = 25;            // wavefront pool capacity = 2^this paths
     int opt_wf_run = 1024;           // pool entries one extend workgroup drains
+    int opt_hot_nodes = 64;          // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
     WfCtl* d_ctl = nullptr;
@@ -593,6 +604,9 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_WF_CAPACITY_LOG2:
         if (value < 10 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^10..2^28 paths");
         ctx->opt_wf_log2 = value; return RT_OK;
+    case RT_OPT_HOT_NODES:
+        if (value < 0 || value > 512) return fail(RT_ERR_INVALID, "rt_set_option: hot nodes must be 0..512");
+        ctx->opt_hot_nodes = value; return RT_OK;
     case RT_OPT_WF_RUN:
         if (value < 256 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: extend run must be 256..2^20 entries");
         ctx->opt_wf_run = value; return RT_OK;
@@ -776,12 +790,14 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
         const dim3 egrid((cap + rpb - 1) / rpb);
         const int tke = timing_begin(ctx, 0, s);
+        const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
+        const size_t elds = stack_bytes(ctx) + 16 + (size_t)n_hot * RT_HOT_STRIDE;
         if (ctx->opt_counters)
-            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, elds, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->d_counters);
         else
-            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, stack_bytes(ctx) + 16, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, elds, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->d_counters);
         timing_end(ctx, tke, s);
         HIP_TRY(hipGetLastError());
         cur = nxt;
