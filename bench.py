@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--wf-run", type=int, default=0)
     ap.add_argument("--wf-burst", type=int, default=0)
     ap.add_argument("--hot-nodes", type=int, default=-1)
+    ap.add_argument("--wf-sort", type=int, default=-1)
+    ap.add_argument("--wf-vote", type=int, default=-1)
+    ap.add_argument("--wf-refill", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
     args = ap.parse_args()
 
     import torch
@@ -102,6 +106,8 @@ def main():
     else:
         asm = scene.luyu(args.width, args.height, FRAME_SPP)
     cfg = asm.config
+    if args.depth:
+        cfg.max_depth = args.depth
     objs = scene.finalize(asm)
     t_build = time.time() - t0
     ctx = capi.Context(device_index)
@@ -121,6 +127,12 @@ def main():
         ctx.set_option(capi.OPT_WF_RUN, args.wf_run)
     if args.wf_burst:
         ctx.set_option(capi.OPT_WF_BURST, args.wf_burst)
+    if args.wf_sort >= 0:
+        ctx.set_option(capi.OPT_WF_SORT, args.wf_sort)
+    if args.wf_vote >= 0:
+        ctx.set_option(capi.OPT_WF_VOTE, args.wf_vote)
+    if args.wf_refill:
+        ctx.set_option(capi.OPT_WF_REFILL, args.wf_refill)
     if args.hot_nodes >= 0:
         ctx.set_option(capi.OPT_HOT_NODES, args.hot_nodes)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
@@ -234,8 +246,9 @@ def main():
                 traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # every 16-byte piece a lane loads is one access of the CU's vector L1, which serves about one per clock
-        l1_accesses_per_ray = 8.0 * mix["box_tests_per_ray"] / max(1e-9, mix["boxes_per_node_visit"]) + 3.0 * mix["tri_tests_per_ray"] + 4.0
+        # every 16-byte piece a lane loads from memory is one access of the CU's vector L1, which serves about one per
+        # clock; node records the workgroup holds in LDS do not go through it
+        l1_accesses_per_ray = (8.0 * mix["node_visits_per_ray"] * (1.0 - mix["node_visits_from_lds"]) + 3.0 * mix["tri_tests_per_ray"] + 4.0)
         out = {
             "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -258,7 +271,8 @@ def main():
                              "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},
             "l1_access_bound": {"accesses_per_ray": round(l1_accesses_per_ray, 1),
                                 "achieved_G_per_s": round(my_rays * l1_accesses_per_ray / max(1e-9, k_ms_total * 1e-3) / 1e9, 1),
-                                "peak_G_per_s": 256 * 2.4, "note": "one 16-byte lane access per clock per CU (tools/microbench/gather.hip)"},
+                                "peak_G_per_s": 256 * 2.4, "frac": round(my_rays * l1_accesses_per_ray / max(1e-9, k_ms_total * 1e-3) / 1e9 / (256 * 2.4), 4),
+                                "note": "one 16-byte lane access per clock per CU (tools/microbench/gather.hip); LDS-served node visits excluded"},
             "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},
         }
         if world == 1 and not args.no_cpu_baseline:

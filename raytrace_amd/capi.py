@@ -35,7 +35,10 @@ CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, 
 CNT_COUNT = 16
 OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS, OPT_MODE, OPT_WF_CAPACITY_LOG2, OPT_WF_RUN, OPT_WF_BURST = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_TIMING = 11
+OPT_WF_SORT = 10
 OPT_HOT_NODES = 12
+OPT_WF_VOTE = 13
+OPT_WF_REFILL = 14
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 
 

@@ -39,6 +39,7 @@ struct PathParams {
     int tiles_x, tiles_y;
     int xcd_remap;
     int lds_slots;                        // stack levels kept in LDS
+    int sort_rays;                        // wavefront: order each workgroup's surviving rays by direction octant
 };
 
 #define RT_BLOCK 256

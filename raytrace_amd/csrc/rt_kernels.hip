@@ -190,6 +190,8 @@ struct WfCtl {
     uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
+    uint32_t queue_next;            // closest-hit launch: first pool entry no wave has claimed yet
+    uint32_t pad;
 };
 
 __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity) {
@@ -204,6 +206,7 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
     ctl->cursor += n;
     ctl->count[nxt] = have + n;
     ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
+    ctl->queue_next = 0;
 }
 
 // Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
@@ -249,76 +252,100 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 }
 
 // Closest hit for every pooled path.  Traversal lengths differ wildly between the rays of a wave, so a lane does
-// not own one ray: each workgroup owns a run of `rays_per_block` pool entries and every lane that finishes a
-// ray stores its hit and claims the next entry of the run (64-bit ballot of the idle lanes, one LDS atomic per
-// wave, lane prefix count), until the run is drained.  The inner-node loop runs at most `node_burst` trips
-// before the wave looks at leaves and idle lanes again.
+// not own one ray and a wave does not own a fixed share of the pool: the launch fills the chip once, every wave
+// claims `chunk` consecutive pool entries at a time from one queue word (one returning atomic per chunk) and
+// every lane that finishes a ray stores its hit and takes the next entry of its wave's chunk (64-bit ballot of
+// the idle lanes, lane prefix count).  Lanes only run dry once, when the whole pool is drained.
+// Which visit the wave runs next: `vote_leaf_weight` == 0 -> at most `node_burst` node trips, then one leaf trip;
+// k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
+// lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const WfCtl* __restrict__ ctl, WfPools pools, int nxt,
-                                                             int lds_slots, uint32_t rays_per_block, int node_burst, uint32_t n_hot,
+__global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
+                                                             int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
+                                                             int vote_leaf_weight, int refill_min,
                                                              unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
-    // the run cursor sits behind the stacks, inside the one dynamic LDS block
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    lds_u32* run_next = (lds_u32*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK);
-    // behind the cursor: LDS copies of the first n_hot node records
-    lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK + 2);
+    // behind the stacks, inside the one dynamic LDS block: copies of the first n_hot node records
+    lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK);
     const uint32_t count = ctl->count[nxt];
-    const uint32_t run_begin = blockIdx.x * rays_per_block;
-    const uint32_t run_end = min(count, run_begin + rays_per_block);
     TravCounters tc = {};
-    if (run_begin < count) {                       // uniform for the workgroup
-        if (threadIdx.x == 0) *run_next = run_begin;
-        for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += RT_BLOCK)
-        {
-            const float4 v = reinterpret_cast<const float4*>(sc.nodes)[k];
-            f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
-            hot[(k >> 3) * (RT_HOT_STRIDE / 16) + (k & 7u)] = o;
+    for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += RT_BLOCK) {
+        const float4 v = reinterpret_cast<const float4*>(sc.nodes)[k];
+        f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+        hot[(k >> 3) * (RT_HOT_STRIDE / 16) + (k & 7u)] = o;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    Walker<COUNT> w;
+    w.init(stack, RT_BLOCK, lds_slots);
+    w.set_hot(hot, n_hot);
+    RayD r;
+    ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
+    Hit h;
+    h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+    int ridx = -1;                                 // pool entry this lane is tracing, -1 = none
+    uint32_t next = 0, end = 0;                    // wave-uniform: the unclaimed rest of this wave's chunk
+    bool exhausted = false;                        // wave-uniform: the queue has nothing left
+    // hand the idle lanes `m` the next entries of the wave's chunk, claiming a new chunk when it is used up
+    auto refill = [&](unsigned long long m, bool idle) {
+        if (next >= end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->queue_next, chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= count) { exhausted = true; return; }
+            next = base;
+            end = min(count, base + chunk);
         }
-        __syncthreads();
-        const int lane = threadIdx.x & 63;
-        Walker<COUNT> w;
-        w.init(stack, RT_BLOCK, lds_slots);
-        w.set_hot(hot, n_hot);
-        RayD r;
-        ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
-        Hit h;
-        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-        int ridx = -1;                             // pool entry this lane is tracing, -1 = none
-        for (;;) {
-            const bool idle = w.done();
-            if (idle && ridx >= 0) {
-                pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
-                ridx = -1;
-            }
-            const unsigned long long m = __ballot(idle);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd((uint32_t*)run_next, (uint32_t)__popcll(m));
-                base = __shfl(base, leader, 64);
-                if (idle) {
-                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (idx < run_end) {
-                        const float4 a = pools.p0[nxt][idx], b = pools.p1[nxt][idx];
-                        const int depth = __float_as_int(pools.p2[nxt][idx].w);
-                        ridx = (int)idx;
-                        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-                        if (depth > 0) {           // lanes outside the image carry depth < 0: their hit stays "none"
-                            ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
-                            w.begin(sc, r, h, tc);
-                        }
-                    }
+        if (idle) {
+            const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (idx < end) {
+                const float4 a = pools.p0[nxt][idx], b = pools.p1[nxt][idx];
+                const int depth = __float_as_int(pools.p2[nxt][idx].w);
+                ridx = (int)idx;
+                h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+                if (depth > 0) {                   // lanes outside the image carry depth < 0: their hit stays "none"
+                    ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+                    w.begin(sc, r, h, tc);
                 }
             }
-            if (!__any(ridx >= 0)) break;
+        }
+        next = min(end, next + (uint32_t)__popcll(m));
+    };
+    for (;;) {
+        const bool idle = w.done();
+        if (idle && ridx >= 0) {
+            pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+            ridx = -1;
+        }
+        const unsigned long long m = __ballot(idle);
+        if (vote_leaf_weight == 0) {
+            if (m && !exhausted) refill(m, idle);
+            if (!__any(ridx >= 0)) {
+                if (exhausted) break;              // nothing in flight and nothing left to claim
+                continue;
+            }
             int burst = node_burst;
             while (w.at_inner()) {
                 w.node_step(sc, r, h, tc);
                 if (--burst == 0) break;
             }
             if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
+        } else {
+            const int n_node = __popcll(__ballot(w.at_inner())), n_leaf = __popcll(__ballot(w.at_leaf()));
+            if (m && !exhausted && ((int)__popcll(m) >= refill_min || n_node + n_leaf == 0)) {
+                refill(m, idle);
+                continue;                          // count again: the new rays may be anywhere
+            }
+            if (n_node + n_leaf == 0) {
+                if (__any(ridx >= 0)) continue;    // rays that ended at once (missed the root box): store them next trip
+                break;
+            }
+            if (n_node * 16 >= n_leaf * vote_leaf_weight) {
+                if (w.at_inner()) w.node_step(sc, r, h, tc);
+            } else {
+                if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
+            }
         }
     }
     if (COUNT) add_trav_counters(counters, tc);
@@ -330,7 +357,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, const 
 #define RT_SHADE_BLOCK 1024
 template <bool COUNT>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
-    __shared__ uint32_t wave_survivors[RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t bin_count[8 * (RT_SHADE_BLOCK / 64)];   // survivors per [direction octant][wave], then their offsets
     __shared__ uint32_t wave_finished[RT_SHADE_BLOCK / 64];
     __shared__ uint32_t block_base;
     const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
@@ -373,32 +400,48 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             }
         }
     }
-    // queue compaction: 64-bit ballot per wave, wave totals through LDS, one atomic per workgroup, lane prefix count
-    const unsigned long long mask = __ballot(survives);
+    // Queue compaction, ordered by direction octant: the workgroup's survivors leave in 8 groups (sign bits of the
+    // new direction), so that the waves of the next closest-hit launch hold rays that start close together (same
+    // few pixel tiles) AND point the same way -- they then walk the same nodes.  Per wave: one 64-bit ballot per
+    // octant; counts [octant][wave] through LDS; wave 0 turns them into offsets with one shuffle scan; one returning
+    // atomic per workgroup.  With pp.sort_rays == 0 every survivor is filed under octant 0: plain order.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t oct = 0;
+    if (survives && pp.sort_rays) oct = (o0.w < 0.0f ? 1u : 0u) | (o1.x < 0.0f ? 2u : 0u) | (o1.y < 0.0f ? 4u : 0u);
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < 8u; o++) {
+        const unsigned long long m = __ballot(survives && oct == o);
+        if (lane == 0) bin_count[o * (RT_SHADE_BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+        if (survives && oct == o) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    }
     const unsigned long long done = __ballot(n_paths != 0);
     const unsigned long long traced = __ballot(n_rays != 0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        wave_survivors[wave] = (uint32_t)__popcll(mask);
-        wave_finished[wave] = (uint32_t)__popcll(done) | ((uint32_t)__popcll(traced) << 16);   // both <= 64
-    }
+    if (lane == 0) wave_finished[wave] = (uint32_t)__popcll(done) | ((uint32_t)__popcll(traced) << 16);   // both <= 64
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0, fin = 0, rays = 0;
-        for (int k = 0; k < RT_SHADE_BLOCK / 64; k++) {
-            total += wave_survivors[k];
-            fin += wave_finished[k] & 0xFFFFu;
-            rays += wave_finished[k] >> 16;
+    if (wave == 0) {
+        // 128 counts, octant-major: lane l owns entries 2l and 2l+1
+        const uint32_t c0 = bin_count[2 * lane], c1 = bin_count[2 * lane + 1];
+        uint32_t incl = c0 + c1;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
         }
-        block_base = total ? atomicAdd(&ctl->count[nxt], total) : 0u;
-        if (fin) atomicAdd(pp.counters + RT_CNT_PATHS, (unsigned long long)fin);
-        if (rays) atomicAdd(pp.counters + RT_CNT_RAYS, (unsigned long long)rays);   // one closest-hit query was traced per live path
+        const uint32_t excl = incl - (c0 + c1);
+        bin_count[2 * lane] = excl;
+        bin_count[2 * lane + 1] = excl + c0;
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint32_t fr = lane < RT_SHADE_BLOCK / 64 ? wave_finished[lane] : 0u;   // packed sums stay below 2^16 each
+        for (int d = 32; d > 0; d >>= 1) fr += __shfl_xor(fr, d, 64);
+        if (lane == 0) {
+            block_base = total ? atomicAdd(&ctl->count[nxt], total) : 0u;
+            const uint32_t fin = fr & 0xFFFFu, rays = fr >> 16;
+            if (fin) atomicAdd(pp.counters + RT_CNT_PATHS, (unsigned long long)fin);
+            if (rays) atomicAdd(pp.counters + RT_CNT_RAYS, (unsigned long long)rays);   // one closest-hit query was traced per live path
+        }
     }
     __syncthreads();
     if (survives) {
-        uint32_t pos = block_base;
-        for (int k = 0; k < wave; k++) pos += wave_survivors[k];
-        pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const uint32_t pos = block_base + bin_count[oct * (RT_SHADE_BLOCK / 64) + wave] + rank;
         pools.p0[nxt][pos] = o0;
         pools.p1[nxt][pos] = o1;
         pools.p2[nxt][pos] = o2;
@@ -499,10 +542,14 @@ struct rt_context {
     uint64_t time_launches[3] = {0, 0, 0};
     int opt_mode = 1;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
     int opt_wf_log2 = 25;            // wavefront pool capacity = 2^this paths
-    int opt_wf_run = 1024;           // pool entries one extend workgroup drains
-    int opt_hot_nodes = 64;          // node records (breadth-first prefix) the extend kernel keeps in LDS
+    int opt_wf_run = 256;            // pool entries a closest-hit wave claims from the queue at a time
+    int opt_wf_sort = 1;             // shade kernel files surviving rays by direction octant
+    int opt_wf_vote = 32;            // 0 = fixed node burst; k > 0 = per-trip vote, a leaf visit weighs k/16 node visits
+    int opt_wf_refill = 16;          // vote policy: idle lanes that trigger a refill
+    int opt_hot_nodes = 32;          // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
+    int n_cu = 256;                  // compute units of the device
     WfCtl* d_ctl = nullptr;
     WfCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots
     hipEvent_t ctl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -572,6 +619,8 @@ int rt_create(int device_id, rt_context** out) {
     HIP_TRY(hipSetDevice(device_id));
     rt_context* c = new rt_context();
     c->device = device_id;
+    (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
+    if (c->n_cu <= 0) c->n_cu = 256;
     hipError_t e = hipMalloc((void**)&c->d_counters, RT_CNT_COUNT * sizeof(unsigned long long));
     if (e != hipSuccess) { delete c; return fail(RT_ERR_DEVICE, std::string("hipMalloc counters: ") + hipGetErrorString(e)); }
     (void)hipMemset(c->d_counters, 0, RT_CNT_COUNT * sizeof(unsigned long long));
@@ -604,11 +653,18 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_WF_CAPACITY_LOG2:
         if (value < 10 || value > 28) return fail(RT_ERR_INVALID, "rt_set_option: wavefront capacity must be 2^10..2^28 paths");
         ctx->opt_wf_log2 = value; return RT_OK;
+    case RT_OPT_WF_SORT: ctx->opt_wf_sort = value ? 1 : 0; return RT_OK;
+    case RT_OPT_WF_VOTE:
+        if (value < 0 || value > 1024) return fail(RT_ERR_INVALID, "rt_set_option: vote weight must be 0..1024");
+        ctx->opt_wf_vote = value; return RT_OK;
+    case RT_OPT_WF_REFILL:
+        if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "rt_set_option: refill threshold must be 1..64 lanes");
+        ctx->opt_wf_refill = value; return RT_OK;
     case RT_OPT_HOT_NODES:
         if (value < 0 || value > 512) return fail(RT_ERR_INVALID, "rt_set_option: hot nodes must be 0..512");
         ctx->opt_hot_nodes = value; return RT_OK;
     case RT_OPT_WF_RUN:
-        if (value < 256 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: extend run must be 256..2^20 entries");
+        if (value < 64 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: closest-hit chunk must be 64..2^20 entries");
         ctx->opt_wf_run = value; return RT_OK;
     case RT_OPT_WF_BURST:
         if (value < 1 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: node burst must be >= 1");
@@ -787,17 +843,19 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         }
         hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
+        // one launch fills the chip once (8 workgroups of 4 waves per CU at most); the waves share out the pool themselves
         const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
-        const dim3 egrid((cap + rpb - 1) / rpb);
+        const uint32_t wanted = (cap + rpb * (RT_BLOCK / 64) - 1) / (rpb * (RT_BLOCK / 64));
+        const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * 8u));
         const int tke = timing_begin(ctx, 0, s);
         const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
-        const size_t elds = stack_bytes(ctx) + 16 + (size_t)n_hot * RT_HOT_STRIDE;
+        const size_t elds = stack_bytes(ctx) + (size_t)n_hot * RT_HOT_STRIDE;
         if (ctx->opt_counters)
-            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, elds, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
         else
-            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, elds, s, ctx->dev, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->d_counters);
+            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
+                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
         timing_end(ctx, tke, s);
         HIP_TRY(hipGetLastError());
         cur = nxt;
@@ -858,6 +916,7 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     pp.xcd_remap = ctx->opt_xcd;
     pp.chunk = ctx->opt_chunk;
     pp.lds_slots = lds_slots(ctx);
+    pp.sort_rays = ctx->opt_wf_sort;
     for (int done = 0; done < spp; done += pass) {
         pp.first_sample = first_sample + done;
         pp.n_samples = spp - done < pass ? spp - done : pass;
