@@ -183,10 +183,10 @@ struct Walker {
     int stride, lds_slots;
     lds_float4* hot;
     uint32_t n_hot;
-    uint2 spill[RT_SPILL_SLOTS];
+    uint2* spill;                  // RT_SPILL_SLOTS private entries owned by the caller (kept out of this struct so that its scalars stay in registers)
 
-    __device__ __forceinline__ void init(lds_uint2* stack_, int stride_, int lds_slots_) {
-        stack = stack_; stride = stride_; lds_slots = lds_slots_; cur = REF_NONE; sp = 0;
+    __device__ __forceinline__ void init(lds_uint2* stack_, int stride_, int lds_slots_, uint2* spill_) {
+        stack = stack_; stride = stride_; lds_slots = lds_slots_; spill = spill_; cur = REF_NONE; sp = 0;
         hot = nullptr; n_hot = 0;
     }
 
@@ -280,8 +280,9 @@ struct Walker {
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const SceneDev& sc, const RayD& r, Hit& h, lds_uint2* stack, int stride, int lds_slots,
                                             TravCounters& tc) {
+    uint2 spill[RT_SPILL_SLOTS];
     Walker<COUNT> w;
-    w.init(stack, stride, lds_slots);
+    w.init(stack, stride, lds_slots, spill);
     w.begin(sc, r, h, tc);
     for (;;) {
         while (w.at_inner()) w.node_step(sc, r, h, tc);

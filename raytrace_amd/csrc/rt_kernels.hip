@@ -277,8 +277,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    uint2 spill[RT_SPILL_SLOTS];
     Walker<COUNT> w;
-    w.init(stack, RT_BLOCK, lds_slots);
+    w.init(stack, RT_BLOCK, lds_slots, spill);
     w.set_hot(hot, n_hot);
     RayD r;
     ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
