@@ -91,26 +91,36 @@ __device__ __forceinline__ float u01(uint32_t v) { return (float)v * 2.328306436
 // ---------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 struct RayD {
     float ox, oy, oz;
     float dx, dy, dz;
     float ix, iy, iz;    // 1/d, hoisted out of include/bvh.h:43
+    // the same origin and inverses again as register pairs in the order a box record holds its planes
+    // (min.x min.y | min.z max.x | max.y max.z), so that one packed instruction handles two planes
+    f2v o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
 };
 
 __device__ __forceinline__ void ray_set(RayD& r, v3 o, v3 d) {
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
     r.dx = d.x; r.dy = d.y; r.dz = d.z;
     r.ix = 1.0f / d.x; r.iy = 1.0f / d.y; r.iz = 1.0f / d.z;
+    r.o_xy = (f2v){r.ox, r.oy}; r.o_zx = (f2v){r.oz, r.ox}; r.o_yz = (f2v){r.oy, r.oz};
+    r.i_xy = (f2v){r.ix, r.iy}; r.i_zx = (f2v){r.iz, r.ix}; r.i_yz = (f2v){r.iy, r.iz};
 }
 
-// include/bvh.h:39-58.  The per-axis early exit there is equivalent to one final
-// t0 > t1 test because t0 never decreases and t1 never increases.
-__device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                     const RayD& r, float& t_near) {
-    const float ax = (mnx - r.ox) * r.ix, bx = (mxx - r.ox) * r.ix;
-    const float ay = (mny - r.oy) * r.iy, by = (mxy - r.oy) * r.iy;
-    const float az = (mnz - r.oz) * r.iz, bz = (mxz - r.oz) * r.iz;
-    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+// include/bvh.h:39-58 on a box record as it lies in memory (a = min.x min.y min.z max.x, b = max.y max.z ...).
+// The per-axis early exit there is equivalent to one final t0 > t1 test because t0 never decreases and t1
+// never increases.  The six subtractions and six multiplications run as three packed pairs each -- lane for
+// lane the same IEEE operations as the scalar form.
+__device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near) {
+    const f2v d0 = (a.xy - r.o_xy) * r.i_xy;      // ax, ay
+    const f2v d1 = (a.zw - r.o_zx) * r.i_zx;      // az, bx
+    const f2v d2 = (b.xy - r.o_yz) * r.i_yz;      // by, bz
+    const float ax = d0.x, ay = d0.y, az = d1.x, bx = d1.y, by = d2.x, bz = d2.y;
+    const bool nx = r.i_xy.x < 0.0f, ny = r.i_xy.y < 0.0f, nz = r.i_zx.x < 0.0f;
     float t0 = fmaxf(-RT_INF, nx ? bx : ax);
     float t1 = fminf(RT_INF, nx ? ax : bx);
     t0 = fmaxf(t0, ny ? by : ay);
@@ -118,7 +128,7 @@ __device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx,
     t0 = fmaxf(t0, nz ? bz : az);
     t1 = fminf(t1, nz ? az : bz);
     t_near = t0;
-    return !(t0 > t1) && (t1 > 0.0f);
+    return !(t0 > t1) & (t1 > 0.0f);
 }
 
 struct Hit {
@@ -140,7 +150,7 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
     const float det = e1x * px + e1y * py + e1z * pz;
     bool rej = (det > -1e-6f) && (det < 1e-6f);
     const float inv_det = 1.0f / det;
-    const float tx = r.ox + (-v0x), ty = r.oy + (-v0y), tz = r.oz + (-v0z);
+    const float tx = r.o_xy.x + (-v0x), ty = r.o_xy.y + (-v0y), tz = r.o_zx.x + (-v0z);   // the traversal keeps the origin in its pairs
     const float u = (tx * px + ty * py + tz * pz) * inv_det;
     rej = rej || (u < 0.0f) || (u > 1.0f);
     const float qx = ty * e1z - tz * e1y;
@@ -162,9 +172,7 @@ __device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint
 // children of a node are hit) spill to a per-lane private array, so LDS no longer caps occupancy.
 #define RT_SPILL_SLOTS 56
 typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
-typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f4v lds_float4;   // native vector type: HIP's float4 class cannot be assigned across address spaces
-__device__ __forceinline__ float4 ld_lds4(const lds_float4* p) { const f4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 // LDS copies of hot nodes sit 144 bytes apart (128 + 16): consecutive nodes start 4 banks further on, so lanes that
 // read the same 16-byte piece of different nodes spread over the banks instead of all landing on one bank group.
 #define RT_HOT_STRIDE 144
@@ -200,8 +208,9 @@ struct Walker {
         cur = REF_NONE;
         float tn;
         if (COUNT) tc.n_box++;
-        if (slab(sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0], sc.root.bmax[1], sc.root.bmax[2], r, tn))
-            cur = sc.root.ref;
+        const f4v a = {sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0]};
+        const f4v b = {sc.root.bmax[1], sc.root.bmax[2], 0.0f, 0.0f};
+        if (slab(a, b, r, tn)) cur = sc.root.ref;
     }
 
     // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
@@ -230,13 +239,12 @@ struct Walker {
 
     // visit the two-level node `cur`: one 128-byte record decides up to four grandchildren, slot 0 = visited first
     __device__ __forceinline__ void node_step(const SceneDev& sc, const RayD& r, const Hit& h, TravCounters& tc) {
-        float4 a0, b0, a1, b1, a2, b2, a3, b3;
+        f4v a0, b0, a1, b1, a2, b2, a3, b3;
         if (cur < n_hot) {
             const lds_float4* q = hot + cur * (RT_HOT_STRIDE / 16);
-            a0 = ld_lds4(q); b0 = ld_lds4(q + 1); a1 = ld_lds4(q + 2); b1 = ld_lds4(q + 3);
-            a2 = ld_lds4(q + 4); b2 = ld_lds4(q + 5); a3 = ld_lds4(q + 6); b3 = ld_lds4(q + 7);
+            a0 = q[0]; b0 = q[1]; a1 = q[2]; b1 = q[3]; a2 = q[4]; b2 = q[5]; a3 = q[6]; b3 = q[7];
         } else {
-            const float4* q = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const f4v* q = reinterpret_cast<const f4v*>(sc.nodes + cur);
             a0 = q[0]; b0 = q[1]; a1 = q[2]; b1 = q[3]; a2 = q[4]; b2 = q[5]; a3 = q[6]; b3 = q[7];
         }
         const uint32_t r0 = __float_as_uint(b0.z), r1 = __float_as_uint(b1.z), r2 = __float_as_uint(b2.z), r3 = __float_as_uint(b3.z);
@@ -247,11 +255,12 @@ struct Walker {
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }
+        // all four slots are tested without branches: an unused slot costs a few wasted operations, a branch per slot costs more
         float t0, t1, t2, t3;
-        const bool h0 = (r0 != REF_NONE) && slab(a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, r, t0) && !(t0 > h.t);
-        const bool h1 = (r1 != REF_NONE) && slab(a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, r, t1) && !(t1 > h.t);
-        const bool h2 = (r2 != REF_NONE) && slab(a2.x, a2.y, a2.z, a2.w, b2.x, b2.y, r, t2) && !(t2 > h.t);
-        const bool h3 = (r3 != REF_NONE) && slab(a3.x, a3.y, a3.z, a3.w, b3.x, b3.y, r, t3) && !(t3 > h.t);
+        const bool h0 = (r0 != REF_NONE) & slab(a0, b0, r, t0) & !(t0 > h.t);
+        const bool h1 = (r1 != REF_NONE) & slab(a1, b1, r, t1) & !(t1 > h.t);
+        const bool h2 = (r2 != REF_NONE) & slab(a2, b2, r, t2) & !(t2 > h.t);
+        const bool h3 = (r3 != REF_NONE) & slab(a3, b3, r, t3) & !(t3 > h.t);
         // The first hit slot is visited now; later hit slots wait on the stack, last slot deepest.  A slot whose
         // t_near already exceeds the best t is dropped now: the best t only shrinks (upstream would drop it at pop time).
         if (h3 && (h0 || h1 || h2)) push(r3, t3, tc);
