@@ -8,9 +8,42 @@ HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra
 
 LIB := raytrace_amd/librtcore.so
 
-all: $(LIB) oracle
+# Host side above the C ABI (scene loader, worker, CLI, HTTP server) and the small tools the tests drive.
+HOST     := raytrace_amd/host
+HOSTCXX  ?= g++
+HOSTCXXFLAGS := -std=c++17 -O2 -ffp-contract=off -Wall -Wextra -Iinclude -I$(HOST)
+HOST_OBJS := $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/scene_loader.o $(HOST)/worker.o $(HOST)/http_server.o
+BINS     := bin/main bin/server bin/obj_dump bin/scene_dump bin/png_tool
+RPATH    := -Wl,-rpath,'$$ORIGIN/../raytrace_amd'
 
-$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
+all: $(LIB) oracle host
+
+host: $(BINS)
+
+$(HOST)/%.o: $(HOST)/%.cpp $(wildcard $(HOST)/*.h) include/rtcore.h
+	$(HOSTCXX) $(HOSTCXXFLAGS) -c -o $@ $<
+
+bin/main: $(HOST)/main.cpp $(HOST_OBJS) $(LIB)
+	@mkdir -p bin
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $(HOST)/main.cpp $(HOST_OBJS) -Lraytrace_amd -lrtcore -lz -lpthread $(RPATH)
+
+bin/server: $(HOST)/server.cpp $(HOST_OBJS) $(LIB)
+	@mkdir -p bin
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $(HOST)/server.cpp $(HOST_OBJS) -Lraytrace_amd -lrtcore -lz -lpthread $(RPATH)
+
+bin/obj_dump: tools/host/obj_dump.cpp $(HOST)/obj_model.o
+	@mkdir -p bin
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $^
+
+bin/png_tool: tools/host/png_tool.cpp $(HOST)/image_io.o
+	@mkdir -p bin
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $^ -lz
+
+bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(LIB)
+	@mkdir -p bin
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o -Lraytrace_amd -lrtcore -lz $(RPATH)
+
+$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
@@ -26,7 +59,7 @@ resource-usage:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(CSRC)/rt_kernels.hip
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB)
+	rm -f $(CSRC)/*.o $(HOST)/*.o $(LIB) $(BINS)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean resource-usage
+.PHONY: all oracle host clean resource-usage

@@ -63,6 +63,7 @@ class Assembled:
     materials: np.ndarray = None
     textures: list = field(default_factory=list)     # uint8 (h, w, 4), rows bottom-up
     names: list = field(default_factory=list)
+    blocks: list = field(default_factory=list)       # the object blocks this was assembled from (raytrace_amd.scene_files writes them out)
 
     @property
     def n_triangles(self):
@@ -86,7 +87,7 @@ def _face_normals(pos):
 def assemble(config, blocks):
     """SceneLoader::load_object for each block: one upstream object per non-empty shape; materials =
     base material, then one per MTL record unless simple_material (sceneloader.cpp:132-219)."""
-    out = Assembled(config=config)
+    out = Assembled(config=config, blocks=list(blocks))
     mats = []
     for blk in blocks:
         base_type = TYPE_BY_NAME[blk.type]
