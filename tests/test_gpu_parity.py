@@ -322,3 +322,43 @@ def test_full_size_primary_hits_agree_with_oracle_sample(gpu_ctx):
     assert np.array_equal(go[sel], o) and np.array_equal(gt[sel], t) and same_f32(gtt[sel], tt)
     assert same_f32(gu[sel], u) and same_f32(gv[sel], v)
     assert 0.3 < (go >= 0).mean() <= 1.0
+
+
+def test_rmse_to_a_converged_image(gpu_ctx):
+    """Statistical agreement, seed-independent: GPU frames with one seed against an oracle frame with another seed and
+    many more samples.  The error must fall like 1/sqrt(spp) (tolerance: a 16x sample count must cut the RMSE by at
+    least 2.8x; 4x is the expectation) and stay below 0.03 of the picture's mean at 1024 spp."""
+    asm = scene.material_box(width=48, height=32, n_samples=2048)
+    asm.config.gamma = 1.0
+    p = Pair(gpu_ctx, asm)
+    params = orc.make_params(p.cfg, 0xC0FFEE, 16)
+    ref, _ = p.oracle.render(params, 0, 2048)
+    ref = orc.post_process(ref, 2048, 1.0)                     # mean radiance per pixel, clamped to [0, 1]
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    try:
+        rmse = {}
+        for spp in (64, 1024):
+            got, _ = p.gpu_render(0, spp, 16, counters=False)  # seed of the Pair, different from the oracle's
+            got = orc.post_process(got, spp, 1.0)
+            rmse[spp] = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+    assert rmse[1024] < rmse[64] / 2.8, rmse
+    assert rmse[1024] < 0.03 * float(ref.mean()) + 0.01, (rmse, float(ref.mean()))
+
+
+def test_full_size_sample_split_sums_to_the_whole_frame(gpu_ctx):
+    """Size-independent property at the benchmark's full frame: tracing samples [0,16) and [16,32) into one buffer, in
+    either kernel design, gives exactly the buffer of one 32-sample call (what the multi-GPU split relies on)."""
+    p = Pair(gpu_ctx, scene.formula1(width=2000, height=1200, n_samples=32, detail=0.3, tex_size=256))
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 24)
+    try:
+        whole, cnt = p.gpu_render(0, 32, 16, counters=False)
+        part, _ = p.gpu_render(0, 16, 16, counters=False)
+        part, _ = p.gpu_render(16, 16, 16, accum=part, counters=False)
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(whole, part)
+    assert cnt[capi.CNT_PATHS] == 2000 * 1200 * 32 and np.isfinite(whole).all() and whole.mean() > 0
