@@ -188,6 +188,11 @@ def main():
            "boxes_per_node_visit": 0.0,
            "wave_node_trips_per_ray": c[capi.CNT_WAVE_NODE_TRIPS] * 64 / rays_i,
            "wave_leaf_trips_per_ray": c[capi.CNT_WAVE_LEAF_TRIPS] * 64 / rays_i}
+    if c[capi.CNT_CYC_WAVE]:
+        mix["wave_time_split"] = {"refill": round(c[capi.CNT_CYC_REFILL] / c[capi.CNT_CYC_WAVE], 4), "node": round(c[capi.CNT_CYC_NODE] / c[capi.CNT_CYC_WAVE], 4),
+                                  "leaf": round(c[capi.CNT_CYC_LEAF] / c[capi.CNT_CYC_WAVE], 4),
+                                  "node_cycles_per_trip": round(c[capi.CNT_CYC_NODE] / max(1, c[capi.CNT_WAVE_NODE_TRIPS]), 1),
+                                  "leaf_cycles_per_trip": round(c[capi.CNT_CYC_LEAF] / max(1, c[capi.CNT_WAVE_LEAF_TRIPS]), 1)}
     mix["node_visits_from_lds"] = round(c[capi.CNT_HOT_VISITS] / max(1, c[capi.CNT_NODE_VISITS]), 4)
     mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]

@@ -107,6 +107,10 @@ enum {
     RT_CNT_WAVE_LEAF_TRIPS,   /* leaf-phase trips executed per wave, summed (RT_OPT_COUNTERS) */
     RT_CNT_NODE_VISITS,       /* two-level nodes fetched, summed over lanes (RT_OPT_COUNTERS) */
     RT_CNT_HOT_VISITS,        /* of those, the ones served from the workgroup's LDS copy (RT_OPT_HOT_NODES) */
+    RT_CNT_CYC_REFILL,        /* wavefront closest-hit, per wave and summed (RT_OPT_COUNTERS): clock cycles spent in refill trips, */
+    RT_CNT_CYC_NODE,          /* ... in node trips, */
+    RT_CNT_CYC_LEAF,          /* ... in leaf trips, */
+    RT_CNT_CYC_WAVE,          /* ... and from a wave's first trip to its last (s_memtime, 100 MHz-independent shader clock) */
     RT_CNT_COUNT = 16
 };
 

@@ -136,11 +136,9 @@ struct Hit {
     uint32_t tri;      // packed triangle index, REF_NONE when nothing was hit
 };
 
-// cuda/raytrace.cu:24-42 on a packed record (e1, e2 precomputed).  Rejections keep
+// cuda/raytrace.cu:24-42 on a packed record (e1, e2 precomputed), already in registers.  Rejections keep
 // upstream's comparison polarity so that NaNs fall the same way.
-__device__ __forceinline__ void tri_test(const TriIsect* __restrict__ tris, uint32_t p, const RayD& r, Hit& h) {
-    const float4* q = reinterpret_cast<const float4*>(tris + p);
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+__device__ __forceinline__ void tri_test(float4 q0, float4 q1, float4 q2, uint32_t p, const RayD& r, Hit& h) {
     const float v0x = q0.x, v0y = q0.y, v0z = q0.z;
     const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
     const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
@@ -280,8 +278,11 @@ struct Walker {
             tc.n_tri += (cur & REF_PAIR) ? 2u : 1u;
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_leaf++;
         }
-        tri_test(sc.isect, p, r, h);
-        if (cur & REF_PAIR) tri_test(sc.isect, p + 1, r, h);
+        // both records are fetched at once (one memory round trip per leaf visit, not two); the array ends with a spare record
+        const float4* q = reinterpret_cast<const float4*>(sc.isect + p);
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[3], b1 = q[4], b2 = q[5];
+        tri_test(a0, a1, a2, p, r, h);
+        if (cur & REF_PAIR) tri_test(b0, b1, b2, p + 1, r, h);
         cur = pop(h);
     }
 };

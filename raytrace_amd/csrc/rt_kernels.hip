@@ -185,13 +185,15 @@ struct WfPools {
     float4* hit;        // t, u, v, packed triangle (written by extend for the pool it ran on)
 };
 
+#define RT_QUEUES 8u
+#define RT_QUEUE_STRIDE 32u
 struct WfCtl {
     uint32_t count[2];              // paths in pool 0 / 1
     uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
-    uint32_t queue_next;            // closest-hit launch: first pool entry no wave has claimed yet
-    uint32_t pad;
+    uint32_t pad[2];
+    uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per region, first entry no wave has claimed yet (one cache line each)
 };
 
 __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity) {
@@ -206,7 +208,7 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
     ctl->cursor += n;
     ctl->count[nxt] = have + n;
     ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
-    ctl->queue_next = 0;
+    for (uint32_t k = 0; k < RT_QUEUES; k++) ctl->queue_next[k * RT_QUEUE_STRIDE] = 0;
 }
 
 // Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 
 // Closest hit for every pooled path.  Traversal lengths differ wildly between the rays of a wave, so a lane does
 // not own one ray and a wave does not own a fixed share of the pool: the launch fills the chip once, every wave
-// claims `chunk` consecutive pool entries at a time from one queue word (one returning atomic per chunk) and
-// every lane that finishes a ray stores its hit and takes the next entry of its wave's chunk (64-bit ballot of
-// the idle lanes, lane prefix count).  Lanes only run dry once, when the whole pool is drained.
+// claims `chunk` consecutive pool entries at a time (one returning atomic per chunk, on the queue word of its XCD's
+// region of the pool) and every lane that finishes a ray stores its hit and takes the next entry of its wave's
+// chunk (64-bit ballot of the idle lanes, lane prefix count).  Lanes only run dry once, when the pool is drained.
 // Which visit the wave runs next: `vote_leaf_weight` == 0 -> at most `node_burst` node trips, then one leaf trip;
 // k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
 // lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
@@ -287,16 +289,30 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
     h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
     int ridx = -1;                                 // pool entry this lane is tracing, -1 = none
     uint32_t next = 0, end = 0;                    // wave-uniform: the unclaimed rest of this wave's chunk
+    uint32_t queue = blockIdx.x & (RT_QUEUES - 1u);  // wave-uniform: the region this wave draws from
+    const uint32_t region = ((count + RT_QUEUES - 1u) / RT_QUEUES + 63u) & ~63u;
     bool exhausted = false;                        // wave-uniform: the queue has nothing left
     // hand the idle lanes `m` the next entries of the wave's chunk, claiming a new chunk when it is used up
     auto refill = [&](unsigned long long m, bool idle) {
         if (next >= end) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctl->queue_next, chunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base >= count) { exhausted = true; return; }
-            next = base;
-            end = min(count, base + chunk);
+            // the pool is cut into RT_QUEUES equal regions with one queue word each; a workgroup starts on the region of
+            // its XCD (workgroups are dealt to the 8 XCDs in turn, so blockIdx & 7 names it) and moves on to the next
+            // region for good when one is drained: each XCD's L2 sees one band of the picture until the very end
+            bool got = false;
+            for (uint32_t tries = 0; tries < RT_QUEUES && !got; tries++) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctl->queue_next[queue * RT_QUEUE_STRIDE], chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t region_begin = min(count, queue * region), region_end = min(count, region_begin + region);
+                if (base < region_end - region_begin) {
+                    next = region_begin + base;
+                    end = min(region_end, next + chunk);
+                    got = true;
+                } else {
+                    queue = (queue + 1u) & (RT_QUEUES - 1u);
+                }
+            }
+            if (!got) { exhausted = true; return; }
         }
         if (idle) {
             const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -313,6 +329,8 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
         }
         next = min(end, next + (uint32_t)__popcll(m));
     };
+    unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0;
+    const unsigned long long cyc_begin = COUNT ? clock64() : 0ull;
     for (;;) {
         const bool idle = w.done();
         if (idle && ridx >= 0) {
@@ -335,21 +353,34 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
         } else {
             const int n_node = __popcll(__ballot(w.at_inner())), n_leaf = __popcll(__ballot(w.at_leaf()));
             if (m && !exhausted && ((int)__popcll(m) >= refill_min || n_node + n_leaf == 0)) {
+                const unsigned long long t0 = COUNT ? clock64() : 0ull;
                 refill(m, idle);
+                if (COUNT) cyc_refill += clock64() - t0;
                 continue;                          // count again: the new rays may be anywhere
             }
             if (n_node + n_leaf == 0) {
                 if (__any(ridx >= 0)) continue;    // rays that ended at once (missed the root box): store them next trip
                 break;
             }
+            const unsigned long long t0 = COUNT ? clock64() : 0ull;
             if (n_node * 16 >= n_leaf * vote_leaf_weight) {
                 if (w.at_inner()) w.node_step(sc, r, h, tc);
+                if (COUNT) cyc_node += clock64() - t0;
             } else {
                 if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
+                if (COUNT) cyc_leaf += clock64() - t0;
             }
         }
     }
-    if (COUNT) add_trav_counters(counters, tc);
+    if (COUNT) {
+        add_trav_counters(counters, tc);
+        if (lane == 0) {       // per wave: cycles inside each kind of trip, and from the first trip to the last
+            atomicAdd(counters + RT_CNT_CYC_REFILL, cyc_refill);
+            atomicAdd(counters + RT_CNT_CYC_NODE, cyc_node);
+            atomicAdd(counters + RT_CNT_CYC_LEAF, cyc_leaf);
+            atomicAdd(counters + RT_CNT_CYC_WAVE, clock64() - cyc_begin);
+        }
+    }
 }
 
 // Workgroups of 1024 lanes: the survivors of all 16 waves are numbered through LDS and the workgroup takes its
@@ -730,6 +761,8 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     uint64_t bytes = 0;
     int rc;
     if ((rc = upload_vec(ps.nodes4, &ctx->d_nodes, bytes))) return rc;
+    const size_t n_packed_tris = ps.isect.size();
+    ps.isect.push_back(TriIsect{});          // one spare record: a leaf visit always fetches two records, the second one unused for a single-triangle leaf
     if ((rc = upload_vec(ps.isect, &ctx->d_isect, bytes))) return rc;
     if ((rc = upload_vec(ps.shade, &ctx->d_shade, bytes))) return rc;
     if ((rc = upload_vec(ps.origin, &ctx->d_origin, bytes))) return rc;
@@ -746,7 +779,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->dev.texels = (const uint32_t*)ctx->d_texels;
     ctx->dev.n_materials = n_materials;
     ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
-    ctx->stats[0] = ps.isect.size();
+    ctx->stats[0] = n_packed_tris;
     ctx->stats[1] = ps.nodes4.size();
     ctx->stats[2] = (uint64_t)ctx->stack_slots;
     ctx->stats[3] = bytes;
