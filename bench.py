@@ -168,12 +168,15 @@ def main():
 
     # ---- instrumented pass: per-ray work mix of this kernel on this workload (not timed) ----
     ctx.set_option(capi.OPT_COUNTERS, 1)
+    ctx.set_option(capi.OPT_TIMING, 1)
     ctx.reset_counters()
     scratch = torch.zeros_like(accum)
     inst_spp = min(spp, 32)
     ctx.raytrace(npix, first_sample(0), inst_spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
                  scratch.data_ptr(), stream)
     c = ctx.counters()
+    tim_i = ctx.timing()
+    ctx.set_option(capi.OPT_TIMING, 0)
     del scratch
     rays_i = max(1, c[capi.CNT_RAYS])
     mix = {"box_tests_per_ray": c[capi.CNT_BOX_TESTS] / rays_i, "tri_tests_per_ray": c[capi.CNT_TRI_TESTS] / rays_i,
@@ -193,6 +196,11 @@ def main():
                                   "leaf": round(c[capi.CNT_CYC_LEAF] / c[capi.CNT_CYC_WAVE], 4),
                                   "node_cycles_per_trip": round(c[capi.CNT_CYC_NODE] / max(1, c[capi.CNT_WAVE_NODE_TRIPS]), 1),
                                   "leaf_cycles_per_trip": round(c[capi.CNT_CYC_LEAF] / max(1, c[capi.CNT_WAVE_LEAF_TRIPS]), 1)}
+    if c[capi.CNT_WAVES] and tim_i["extend_ms"] > 0:
+        # waves of the closest-hit kernel in flight, averaged over its launches (wave life spans / kernel time): the chip holds
+        # 6 x 4 x 256 = 6144 of them, so the shortfall is ramp-up and drain inside the launches
+        mix["extend_mean_waves_in_flight"] = round(c[capi.CNT_WAVE_SPAN_TICKS] * 1e-8 / (tim_i["extend_ms"] * 1e-3), 1)
+        mix["extend_waves_per_launch"] = round(c[capi.CNT_WAVES] / max(1, tim_i["extend_launches"]), 1)
     mix["node_visits_from_lds"] = round(c[capi.CNT_HOT_VISITS] / max(1, c[capi.CNT_NODE_VISITS]), 4)
     mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]

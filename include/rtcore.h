@@ -111,7 +111,9 @@ enum {
     RT_CNT_CYC_NODE,          /* ... in node trips, */
     RT_CNT_CYC_LEAF,          /* ... in leaf trips, */
     RT_CNT_CYC_WAVE,          /* ... and from a wave's first trip to its last (s_memtime, 100 MHz-independent shader clock) */
-    RT_CNT_COUNT = 16
+    RT_CNT_WAVE_SPAN_TICKS,   /* ... the same span in ticks of the constant 100 MHz clock, and */
+    RT_CNT_WAVES,             /* the number of closest-hit waves that ran: with the kernel time, how full the chip was */
+    RT_CNT_COUNT = 24
 };
 
 /* options for rt_set_option */

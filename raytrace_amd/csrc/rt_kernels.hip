@@ -331,6 +331,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
     };
     unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0;
     const unsigned long long cyc_begin = COUNT ? clock64() : 0ull;
+    const unsigned long long tick_begin = COUNT ? wall_clock64() : 0ull;
     for (;;) {
         const bool idle = w.done();
         if (idle && ridx >= 0) {
@@ -379,6 +380,8 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
             atomicAdd(counters + RT_CNT_CYC_NODE, cyc_node);
             atomicAdd(counters + RT_CNT_CYC_LEAF, cyc_leaf);
             atomicAdd(counters + RT_CNT_CYC_WAVE, clock64() - cyc_begin);
+            atomicAdd(counters + RT_CNT_WAVE_SPAN_TICKS, wall_clock64() - tick_begin);
+            atomicAdd(counters + RT_CNT_WAVES, 1ull);
         }
     }
 }
