@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16, help="semantic batch (upstream's <batch_size>)")
-    ap.add_argument("--scene", default="formula1", choices=["formula1", "formula1_glass", "shuttle", "luyu"])
+    ap.add_argument("--scene", default="formula1", choices=["formula1", "formula1_glass", "shuttle", "luyu", "stress"])
     ap.add_argument("--width", type=int, default=2000)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--detail", type=float, default=1.0)
@@ -103,12 +103,16 @@ def main():
         asm = scene.formula1(args.width, args.height, FRAME_SPP, glass=True, detail=args.detail)
     elif args.scene == "shuttle":
         asm = scene.shuttle(args.width, args.height, FRAME_SPP, detail=args.detail)
+    elif args.scene == "stress":
+        # tens of millions of triangles: 64 instances of ~470k-triangle meshes at 3840x2160 unless --width/--height/--detail say otherwise
+        w, h = (3840, 2160) if (args.width, args.height) == (2000, 1200) else (args.width, args.height)
+        asm = scene.stress(w, h, 1024, tris_per_instance=int(470_000 * args.detail))
     else:
         asm = scene.luyu(args.width, args.height, FRAME_SPP)
     cfg = asm.config
     if args.depth:
         cfg.max_depth = args.depth
-    objs = scene.finalize(asm)
+    objs = scene.finalize(asm, progress=(lambda i, n: log(f"  object {i}/{n} transformed, BVH built") if (i % 8 == 0 or i == n) and rank == 0 else None))
     t_build = time.time() - t0
     ctx = capi.Context(device_index)
     ctx.upload_scene(objs, asm.materials, asm.textures)
@@ -314,12 +318,12 @@ def cpu_baseline(asm, objs, args):
 
 
 def save_image(ctx, accum, cfg, spp_done, path):
-    from PIL import Image
+    from raytrace_amd import scene_files
     img = accum.clone()
     ctx.post_process(cfg.width * cfg.height, spp_done, cfg.gamma, img.data_ptr())
     ctx.synchronize()
     a = img.cpu().numpy().reshape(cfg.height, cfg.width, 3)[::-1]
-    Image.fromarray(np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)).save(path)
+    scene_files.write_png_rgb(path, np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8))
 
 
 if __name__ == "__main__":

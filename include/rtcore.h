@@ -113,6 +113,8 @@ enum {
     RT_CNT_CYC_WAVE,          /* ... and from a wave's first trip to its last (s_memtime, 100 MHz-independent shader clock) */
     RT_CNT_WAVE_SPAN_TICKS,   /* ... the same span in ticks of the constant 100 MHz clock, and */
     RT_CNT_WAVES,             /* the number of closest-hit waves that ran: with the kernel time, how full the chip was */
+    RT_CNT_MAX_RAY_VISITS,    /* most node + leaf visits any single ray needed (RT_OPT_COUNTERS) */
+    RT_CNT_NONFINITE_RAYS,    /* rays whose direction has a NaN or infinite component (RT_OPT_COUNTERS) */
     RT_CNT_COUNT = 24
 };
 

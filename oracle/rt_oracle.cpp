@@ -522,7 +522,8 @@ static inline bool material_scatter(const Rng& rng, uint32_t bounce, float decis
         f3 outward_normal;
         float ni_over_nt, cosine;
         // The reference leaves `direction` uninitialised when refraction fails and the
-        // uniform draw equals exactly 1.0 (probability ~2^-25); it is defined as zero here.
+        // uniform draw equals exactly 1.0 (probability ~2^-25 per such event); it is defined here as
+        // the reflection, the value every other draw gives in that case.
         f3 direction = mk(0.0f, 0.0f, 0.0f);
         if (dot3(r.direction, rec.normal) > 0.0f) {
             outward_normal = neg(rec.normal);
@@ -534,9 +535,10 @@ static inline bool material_scatter(const Rng& rng, uint32_t bounce, float decis
             cosine = -dot3(r.direction, rec.normal);
         }
         float reflect_prob;
-        if (refract(r.direction, outward_normal, ni_over_nt, direction)) reflect_prob = schlick(cosine, m.optical_density);
+        const bool refracted = refract(r.direction, outward_normal, ni_over_nt, direction);
+        if (refracted) reflect_prob = schlick(cosine, m.optical_density);
         else reflect_prob = 1.0f;
-        if (decision < reflect_prob) direction = reflect(r.direction, rec.normal);
+        if (decision < reflect_prob || !refracted) direction = reflect(r.direction, rec.normal);
         color = mul3(color, rec.color);
         wo = offset_ray(rec, direction);
         return true;

@@ -176,7 +176,7 @@ typedef __attribute__((address_space(3))) f4v lds_float4;   // native vector typ
 #define RT_HOT_STRIDE 144
 
 struct TravCounters {
-    uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node, n_hot_visit;
+    uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node, n_hot_visit, ray_visits, max_ray_visits, n_nonfinite;
 };
 
 // The walk, one step at a time, so that kernels can interleave it with other work (refilling idle lanes).
@@ -205,10 +205,20 @@ struct Walker {
         sp = 0;
         cur = REF_NONE;
         float tn;
-        if (COUNT) tc.n_box++;
+        if (COUNT) {
+            tc.n_box++;
+            tc.max_ray_visits = max(tc.max_ray_visits, tc.ray_visits);
+            tc.ray_visits = 0;
+            const float sum = r.dx + r.dy + r.dz;
+            tc.n_nonfinite += (sum - sum == 0.0f) ? 0u : 1u;      // a NaN or infinite direction component
+        }
         const f4v a = {sc.root.bmin[0], sc.root.bmin[1], sc.root.bmin[2], sc.root.bmax[0]};
         const f4v b = {sc.root.bmax[1], sc.root.bmax[2], 0.0f, 0.0f};
-        if (slab(a, b, r, tn)) cur = sc.root.ref;
+        // A ray whose direction is exactly zero passes the slab test of every box beyond its origin, so upstream's walk
+        // visits a large part of the tree -- and accepts nothing: d x e2 = 0 makes det = +-0 for every finite triangle,
+        // which the |det| < 1e-6 test rejects (raytrace.cu:27-29).  The answer "no hit" is given without the walk.
+        const bool still = r.dx == 0.0f && r.dy == 0.0f && r.dz == 0.0f;
+        if (!still && slab(a, b, r, tn)) cur = sc.root.ref;
     }
 
     // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)
@@ -249,6 +259,7 @@ struct Walker {
         if (COUNT) {
             tc.n_box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
             tc.n_node++;
+            tc.ray_visits++;
             tc.n_hot_visit += cur < n_hot;
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
@@ -276,6 +287,7 @@ struct Walker {
         const uint32_t p = cur & REF_MASK;
         if (COUNT) {
             tc.n_tri += (cur & REF_PAIR) ? 2u : 1u;
+            tc.ray_visits++;
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_leaf++;
         }
         // both records are fetched at once (one memory round trip per leaf visit, not two); the array ends with a spare record
@@ -461,17 +473,21 @@ __device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& 
                     cosine = -dn;
                 }
                 float reflect_prob = 1.0f;
+                bool refracted = false;
                 {   // refract, raytrace.cu:102-110
                     const float dt = vdot(rd, outward);
                     const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
                     if (disc > 0.0f) {
+                        refracted = true;
                         dir = vsub(vscale(vsub(rd, vscale(outward, dt)), ni_over_nt), vscale(outward, sqrtf(disc)));
                         float r0 = (1.0f - optical_density) / (1.0f + optical_density);   // schlick, :112-116
                         r0 = r0 * r0;
                         reflect_prob = r0 + (1.0f - r0) * powi5(1.0f - cosine);
                     }
                 }
-                if (decision < reflect_prob) dir = reflect3(rd, normal);
+                // Without a refracted direction the ray reflects whatever the draw: upstream leaves the direction
+                // uninitialised when the draw is exactly 1.0 (raytrace.cu:182-187), here that case reflects too.
+                if (decision < reflect_prob || !refracted) dir = reflect3(rd, normal);
                 color = vmul(color, hit_color);
             } else {
                 scattered = false;

@@ -37,6 +37,8 @@ __device__ __forceinline__ void add_trav_counters(unsigned long long* counters, 
     wave_add(counters + RT_CNT_WAVE_LEAF_TRIPS, tc.w_leaf);
     wave_add(counters + RT_CNT_NODE_VISITS, tc.n_node);
     wave_add(counters + RT_CNT_HOT_VISITS, tc.n_hot_visit);
+    wave_add(counters + RT_CNT_NONFINITE_RAYS, tc.n_nonfinite);
+    atomicMax(counters + RT_CNT_MAX_RAY_VISITS, (unsigned long long)max(tc.max_ray_visits, tc.ray_visits));
 }
 
 // ---------------------------------------------------------------------------

@@ -156,17 +156,19 @@ class ProductBackend:
         return capi.build_bvh(tris)
 
 
-def finalize(asm, backend=None):
+def finalize(asm, backend=None, progress=None):
     """Transform every object's triangles and build its BVH (sceneloader.cpp:336-375).
-    Returns [(triangles, nodes)] in upstream layout."""
+    Returns [(triangles, nodes)] in upstream layout.  `progress(i, n)` is called after each object."""
     backend = backend or ProductBackend()
     objs = []
-    for tri, (scale, pos, rot) in zip(asm.triangles, asm.transforms):
+    for i, (tri, (scale, pos, rot)) in enumerate(zip(asm.triangles, asm.transforms)):
         t = tri.copy()
         backend.apply_transform(t, scale, pos, rot)
         nodes = backend.build_bvh(t)
         assert nodes.dtype == NODE_DTYPE
         objs.append((t, nodes))
+        if progress:
+            progress(i + 1, len(asm.triangles))
     return objs
 
 
@@ -224,9 +226,13 @@ def stress(width=3840, height=2160, n_samples=1024, grid=(8, 8), tris_per_instan
     types = ["lambertian", "metal", "refractive", "reflective"]
     blocks = []
     k = 0
+    models = {}              # seven distinct meshes, instanced
     for gy in range(grid[1]):
         for gx in range(grid[0]):
-            m = procgen.blob(tris_per_instance, seed=1 + (k % 7))
+            seed = 1 + (k % 7)
+            if seed not in models:
+                models[seed] = procgen.blob(tris_per_instance, seed=seed)
+            m = models[seed]
             t = types[k % 4]
             blocks.append(ObjectBlock(m, t, position=((gx - grid[0] / 2 + 0.5) * 16.0, (gy - grid[1] / 2 + 0.5) * 16.0, 6.5),
                                       rotation=(17.0 * k % 360, 31.0 * k % 360, 7.0 * k % 360), scale=(6, 6, 6),

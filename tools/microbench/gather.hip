@@ -69,8 +69,11 @@ static void run(const char* name, const float4* tab, uint32_t mask, float* out, 
 }
 
 int main(int argc, char** argv) {
-    const int blocks = 256 * 8, iters = 2000;
-    for (int log2n = 14; log2n <= 24; log2n += (log2n < 20 ? 3 : 2)) {
+    const int blocks = 256 * 8;
+    // optional arguments: largest table as log2 of its record count (default 24 = 1 GB), iterations per lane (default 2000)
+    const int max_log2n = argc > 1 ? atoi(argv[1]) : 24;
+    const int iters = argc > 2 ? atoi(argv[2]) : 2000;
+    for (int log2n = 14; log2n <= max_log2n; log2n += (log2n < 20 ? 3 : 2)) {
         const uint32_t n = 1u << log2n;
         float4* tab; float* out;
         CHECK(hipMalloc(&tab, (size_t)n * 64 + 256));
