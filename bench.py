@@ -43,9 +43,9 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=16, help="semantic batch (upstream's <batch_size>)")
     ap.add_argument("--scene", default="formula1", choices=["formula1", "formula1_glass", "shuttle", "luyu", "stress"])
     ap.add_argument("--width", type=int, default=2000)
@@ -96,6 +96,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- scene (replicated on every rank) ----
+    frame_spp = FRAME_SPP
     t0 = time.time()
     if args.scene == "formula1":
         asm = scene.formula1(args.width, args.height, FRAME_SPP, detail=args.detail)
@@ -107,6 +108,7 @@ def main():
         # tens of millions of triangles: 64 instances of ~470k-triangle meshes at 3840x2160 unless --width/--height/--detail say otherwise
         w, h = (3840, 2160) if (args.width, args.height) == (2000, 1200) else (args.width, args.height)
         asm = scene.stress(w, h, 1024, tris_per_instance=int(470_000 * args.detail))
+        frame_spp = 1024
     else:
         asm = scene.luyu(args.width, args.height, FRAME_SPP)
     cfg = asm.config
@@ -267,16 +269,17 @@ def main():
         # clock; node records the workgroup holds in LDS do not go through it
         l1_accesses_per_ray = (8.0 * mix["node_visits_per_ray"] * (1.0 - mix["node_visits_from_lds"]) + 3.0 * mix["tri_tests_per_ray"] + 4.0)
         out = {
-            "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8",
+            "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
+                      else f"Mrays/s (closest-hit queries), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (procedural stand-in for the formula-1 OBJ, which upstream does not ship)",
             "config": {"workload": f"scene_{args.scene}, {cfg.width}x{cfg.height}, depth {cfg.max_depth}, rr {cfg.russian_roulette}, "
-                                   f"{FRAME_SPP}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
+                                   f"{frame_spp}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
                        "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
                        "mode": args.mode or "library default (wavefront)",
                        "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU"},
-            "seconds_per_frame": round(ms_per_step * 1e-3 * FRAME_SPP / (spp * world), 3),
+            "seconds_per_frame": round(ms_per_step * 1e-3 * frame_spp / (spp * world), 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "gpu_ms_per_step_events": round(float(np.mean(step_ms)), 3) if step_ms else None,
             "work_mix": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mix.items()},

@@ -123,8 +123,8 @@ enum {
     RT_OPT_COUNTERS = 1,      /* 0 = rays/paths only (default), 1 = also box/triangle/shade/texture counts */
     RT_OPT_XCD_REMAP = 2,     /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
-    RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 256);
-                                 scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
+    RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 1024, fewer when the
+                                 buffer would pass 64 GiB); scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
     RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 8); deeper levels spill to private memory */
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.

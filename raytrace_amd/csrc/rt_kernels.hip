@@ -570,7 +570,7 @@ struct rt_context {
     int opt_counters = 0, opt_xcd = 1;
     int opt_lds_slots = 8;           // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
-    int opt_pass = 256;              // samples per pixel held in the slot buffer at once
+    int opt_pass = 1024;             // samples per pixel held in the slot buffer at once (less when that would exceed RT_SLOTS_MAX_BYTES)
     int opt_timing = 0;              // record HIP events around the traversal kernels
     std::vector<hipEvent_t> ev_pool; // event pairs: [2k] before, [2k+1] after
     std::vector<int> ev_kind;        // per pair: 0 = wf_extend, 1 = wf_shade, 2 = path_kernel
@@ -846,6 +846,7 @@ static void timing_collect(rt_context* ctx) {
     ctx->ev_used = 0;
 }
 
+#define RT_SLOTS_MAX_BYTES ((size_t)64 << 30)
 #define RT_CTL_RING 4
 #define RT_CTL_GROUP 4
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.
@@ -931,8 +932,12 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     // slot buffer: one float3 per (sample of the pass, pixel); grown on demand, kept by the context
-    const int pass = spp < ctx->opt_pass ? spp : ctx->opt_pass;
+    // Long passes pay the pipeline's drain (a dozen launches with a thinning pool) less often; the buffer is sized for
+    // a 288 GB device but kept below RT_SLOTS_MAX_BYTES.
     const size_t plane = (size_t)n_pixel * 3 * sizeof(float);
+    int pass = spp < ctx->opt_pass ? spp : ctx->opt_pass;
+    const size_t fit = RT_SLOTS_MAX_BYTES / plane;
+    if (fit >= 2 && (size_t)pass > fit - 1) pass = (int)(fit - 1);
     const size_t need = ((size_t)pass + 1) * plane;
     if (need > ctx->slots_bytes) {
         HIP_TRY(hipStreamSynchronize(s));

@@ -95,8 +95,9 @@ void Worker::render_() {
     rt_device_zero(ctx_, d_buffer_, n_pixels_ * 3 * sizeof(float), nullptr);
     rt_setup_raytrace(ctx_, config.width, config.height, &config.camera_pos.x, &config.camera_dir.x, &config.camera_up.x, config.fov);
     const float ambient[3] = {config.background.x, config.background.y, config.background.z};
-    // whole batches per call; small batches are grouped so that a call carries at least ~128 samples per pixel
-    const int batches_per_slice = std::max(1, 128 / std::max(1, config.batch_size));
+    // whole batches per call; small batches are grouped so that a call carries about 1024 samples per pixel (the
+    // library's pipeline drains once per call, so long calls cost less; progress is printed per call)
+    const int batches_per_slice = std::max(1, 1024 / std::max(1, config.batch_size));
     const int slice = batches_per_slice * config.batch_size;
     int done = 0;
     while (done < config.n_samples) {
