@@ -177,7 +177,7 @@ def main():
     ctx.set_option(capi.OPT_TIMING, 1)
     ctx.reset_counters()
     scratch = torch.zeros_like(accum)
-    inst_spp = min(spp, 32)
+    inst_spp = min(spp, int(os.environ.get("RT_BENCH_INST_SPP", "32")))
     ctx.raytrace(npix, first_sample(0), inst_spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
                  scratch.data_ptr(), stream)
     c = ctx.counters()
@@ -200,12 +200,17 @@ def main():
     if c[capi.CNT_CYC_WAVE]:
         mix["wave_time_split"] = {"refill": round(c[capi.CNT_CYC_REFILL] / c[capi.CNT_CYC_WAVE], 4), "node": round(c[capi.CNT_CYC_NODE] / c[capi.CNT_CYC_WAVE], 4),
                                   "leaf": round(c[capi.CNT_CYC_LEAF] / c[capi.CNT_CYC_WAVE], 4),
+                                  "claim_wait": round(c[capi.CNT_CYC_CLAIM] / c[capi.CNT_CYC_WAVE], 4),
+                                  "cycles_per_claim": round(c[capi.CNT_CYC_CLAIM] / max(1, c[capi.CNT_CLAIMS]), 1),
                                   "node_cycles_per_trip": round(c[capi.CNT_CYC_NODE] / max(1, c[capi.CNT_WAVE_NODE_TRIPS]), 1),
                                   "leaf_cycles_per_trip": round(c[capi.CNT_CYC_LEAF] / max(1, c[capi.CNT_WAVE_LEAF_TRIPS]), 1)}
     if c[capi.CNT_WAVES] and tim_i["extend_ms"] > 0:
         # waves of the closest-hit kernel in flight, averaged over its launches (wave life spans / kernel time): the chip holds
         # 6 x 4 x 256 = 6144 of them, so the shortfall is ramp-up and drain inside the launches
         mix["extend_mean_waves_in_flight"] = round(c[capi.CNT_WAVE_SPAN_TICKS] * 1e-8 / (tim_i["extend_ms"] * 1e-3), 1)
+        if c[capi.CNT_LAUNCH_SLOT_TICKS]:
+            mix["extend_tail_idle_fraction"] = round(c[capi.CNT_TAIL_IDLE_TICKS] / c[capi.CNT_LAUNCH_SLOT_TICKS], 4)
+            mix["extend_launch_span_ms"] = round(c[capi.CNT_LAUNCH_SLOT_TICKS] * 1e-5 / max(1, c[capi.CNT_WAVES]) * (c[capi.CNT_WAVES] / max(1, tim_i["extend_launches"])) , 3)
         mix["extend_waves_per_launch"] = round(c[capi.CNT_WAVES] / max(1, tim_i["extend_launches"]), 1)
     mix["node_visits_from_lds"] = round(c[capi.CNT_HOT_VISITS] / max(1, c[capi.CNT_NODE_VISITS]), 4)
     mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])

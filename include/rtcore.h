@@ -115,6 +115,10 @@ enum {
     RT_CNT_WAVES,             /* the number of closest-hit waves that ran: with the kernel time, how full the chip was */
     RT_CNT_MAX_RAY_VISITS,    /* most node + leaf visits any single ray needed (RT_OPT_COUNTERS) */
     RT_CNT_NONFINITE_RAYS,    /* rays whose direction has a NaN or infinite component (RT_OPT_COUNTERS) */
+    RT_CNT_LAUNCH_SLOT_TICKS, /* closest-hit launches (RT_OPT_COUNTERS): (last wave end - first wave start) x waves that worked, summed, 100 MHz ticks */
+    RT_CNT_TAIL_IDLE_TICKS,   /* ... of which behind waves that ended before the launch's last one */
+    RT_CNT_CYC_CLAIM,         /* closest-hit waves: clock cycles spent waiting for chunk claims (inside the refill cycles), and */
+    RT_CNT_CLAIMS,            /* the number of claims */
     RT_CNT_COUNT = 24
 };
 

@@ -195,11 +195,19 @@ struct WfCtl {
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
     uint32_t pad[2];
+    // closest-hit launch under RT_OPT_COUNTERS: earliest wave start, latest wave end, sum of wave ends (100 MHz ticks), waves that did work
+    unsigned long long t_first, t_last, t_end_sum, n_worked;
     uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per region, first entry no wave has claimed yet (one cache line each)
 };
 
-__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity) {
+__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity, unsigned long long* counters) {
     if (threadIdx.x || blockIdx.x) return;
+    if (ctl->n_worked) {
+        // fold the previous closest-hit launch's wave times: slot-ticks the launch spanned, and those left idle behind waves that ended early
+        counters[RT_CNT_LAUNCH_SLOT_TICKS] += (ctl->t_last - ctl->t_first) * ctl->n_worked;
+        counters[RT_CNT_TAIL_IDLE_TICKS] += ctl->t_last * ctl->n_worked - ctl->t_end_sum;
+    }
+    ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
     const uint32_t have = ctl->count[nxt];
     const unsigned long long left = total - ctl->cursor;
     const uint32_t room = capacity - have;
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
     uint32_t next = 0, end = 0;                    // wave-uniform: the unclaimed rest of this wave's chunk
     uint32_t queue = blockIdx.x & (RT_QUEUES - 1u);  // wave-uniform: the region this wave draws from
     const uint32_t region = ((count + RT_QUEUES - 1u) / RT_QUEUES + 63u) & ~63u;
+    unsigned long long cyc_claim = 0, n_claim = 0;
     bool exhausted = false;                        // wave-uniform: the queue has nothing left
     // hand the idle lanes `m` the next entries of the wave's chunk, claiming a new chunk when it is used up
     auto refill = [&](unsigned long long m, bool idle) {
@@ -302,13 +311,17 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
             // region for good when one is drained: each XCD's L2 sees one band of the picture until the very end
             bool got = false;
             for (uint32_t tries = 0; tries < RT_QUEUES && !got; tries++) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctl->queue_next[queue * RT_QUEUE_STRIDE], chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint32_t region_begin = min(count, queue * region), region_end = min(count, region_begin + region);
+                const uint32_t size = chunk;
+                unsigned long long tc0 = 0;
+                if (COUNT) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tc0 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctl->queue_next[queue * RT_QUEUE_STRIDE], size);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (COUNT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cyc_claim += clock64() - tc0; n_claim++; }
                 if (base < region_end - region_begin) {
                     next = region_begin + base;
-                    end = min(region_end, next + chunk);
+                    end = min(region_end, next + size);
                     got = true;
                 } else {
                     queue = (queue + 1u) & (RT_QUEUES - 1u);
@@ -381,9 +394,18 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl*
             atomicAdd(counters + RT_CNT_CYC_REFILL, cyc_refill);
             atomicAdd(counters + RT_CNT_CYC_NODE, cyc_node);
             atomicAdd(counters + RT_CNT_CYC_LEAF, cyc_leaf);
+            atomicAdd(counters + RT_CNT_CYC_CLAIM, cyc_claim);
+            atomicAdd(counters + RT_CNT_CLAIMS, n_claim);
             atomicAdd(counters + RT_CNT_CYC_WAVE, clock64() - cyc_begin);
-            atomicAdd(counters + RT_CNT_WAVE_SPAN_TICKS, wall_clock64() - tick_begin);
+            const unsigned long long tick_end = wall_clock64();
+            atomicAdd(counters + RT_CNT_WAVE_SPAN_TICKS, tick_end - tick_begin);
             atomicAdd(counters + RT_CNT_WAVES, 1ull);
+            if (tc.n_box) {          // this wave traced something
+                atomicMin(&ctl->t_first, tick_begin);
+                atomicMax(&ctl->t_last, tick_end);
+                atomicAdd(&ctl->t_end_sum, tick_end);
+                atomicAdd(&ctl->n_worked, 1ull);
+            }
         }
     }
 }
@@ -704,7 +726,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
         if (value < 64 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: closest-hit chunk must be 64..2^20 entries");
         ctx->opt_wf_run = value; return RT_OK;
     case RT_OPT_WF_BURST:
-        if (value < 1 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: node burst must be >= 1");
+        if (value < 0 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: node burst must be >= 0");
         ctx->opt_wf_burst = value; return RT_OK;
     case RT_OPT_LDS_SLOTS:
         if (value < 1 || value > 32) return fail(RT_ERR_INVALID, "rt_set_option: LDS stack slots must be 1..32");
@@ -881,7 +903,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
             timing_end(ctx, tk, s);
         }
-        hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap);
+        hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap, ctx->d_counters);
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
         // one launch fills the chip once (8 workgroups of 4 waves per CU at most); the waves share out the pool themselves
         const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
