@@ -212,6 +212,7 @@ def main():
             mix["extend_tail_idle_fraction"] = round(c[capi.CNT_TAIL_IDLE_TICKS] / c[capi.CNT_LAUNCH_SLOT_TICKS], 4)
             mix["extend_launch_span_ms"] = round(c[capi.CNT_LAUNCH_SLOT_TICKS] * 1e-5 / max(1, c[capi.CNT_WAVES]) * (c[capi.CNT_WAVES] / max(1, tim_i["extend_launches"])) , 3)
         mix["extend_waves_per_launch"] = round(c[capi.CNT_WAVES] / max(1, tim_i["extend_launches"]), 1)
+    mix["max_visits_of_one_ray"] = c[capi.CNT_MAX_RAY_VISITS]
     mix["node_visits_from_lds"] = round(c[capi.CNT_HOT_VISITS] / max(1, c[capi.CNT_NODE_VISITS]), 4)
     mix["boxes_per_node_visit"] = c[capi.CNT_BOX_TESTS] / max(1, c[capi.CNT_NODE_VISITS])
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
@@ -263,11 +264,12 @@ def main():
         k_ms = k_ms_total / max(1, k_launches)
         algo_bytes_per_launch = my_rays * k_bytes_per_ray / max(1, k_launches)
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        traffic, prof = None, {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
+                prof = json.load(open(tpath)).get(kname, {})
+                traffic = prof.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # every 16-byte piece a lane loads from memory is one access of the CU's vector L1, which serves about one per
@@ -291,7 +293,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": kname, "kernel_ms_mean": round(k_ms, 4), "launches": int(k_launches),
-                         "bytes_per_ray": round(k_bytes_per_ray, 1), "rays_per_launch": round(my_rays / max(1, k_launches), 1)},
+                         "bytes_per_ray": round(k_bytes_per_ray, 1), "rays_per_launch": round(my_rays / max(1, k_launches), 1),
+                         # from the committed PMC passes of this same command (profiles/r01_traffic.json)
+                         "valu_utilisation": prof.get("valu_utilisation"), "mean_waves_in_flight": prof.get("mean_waves_in_flight"),
+                         "resident_wave_limit": prof.get("resident_wave_limit")},
             "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "shade_ms": round(tim["shade_ms"], 2),
                              "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},
             "l1_access_bound": {"accesses_per_ray": round(l1_accesses_per_ray, 1),
