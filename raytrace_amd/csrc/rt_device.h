@@ -23,6 +23,7 @@ struct SceneDev {
     const TexDev* tex;
     const uint32_t* texels;
     int n_materials;
+    uint32_t last_tri;        // the triangle a walk that enters every box tests last (REF_NONE in an empty scene)
 };
 
 struct PathParams {
@@ -218,7 +219,17 @@ struct Walker {
         // visits a large part of the tree -- and accepts nothing: d x e2 = 0 makes det = +-0 for every finite triangle,
         // which the |det| < 1e-6 test rejects (raytrace.cu:27-29).  The answer "no hit" is given without the walk.
         const bool still = r.dx == 0.0f && r.dy == 0.0f && r.dz == 0.0f;
-        if (!still && slab(a, b, r, tn)) cur = sc.root.ref;
+        // A ray whose three direction components are NaN enters every box (NaN products drop out of the slab test) and
+        // passes every triangle test (det is NaN, every rejection compares false; raytrace.cu:27-41), each acceptance
+        // overwriting the one before: upstream's answer is the triangle its walk tests last, with that test's NaN
+        // t, u, v.  That one test is done here; the walk over the whole tree is not.
+        const bool lost = (r.dx != r.dx) && (r.dy != r.dy) && (r.dz != r.dz);
+        if (lost) {
+            if (sc.last_tri != REF_NONE) {
+                const float4* q = reinterpret_cast<const float4*>(sc.isect + sc.last_tri);
+                tri_test(q[0], q[1], q[2], sc.last_tri, r, h);
+            }
+        } else if (!still && slab(a, b, r, tn)) cur = sc.root.ref;
     }
 
     // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)

@@ -377,6 +377,15 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
         ps.max_depth = need;
         renumber_breadth_first(ps);
     }
+    // The triangle tested last by a walk that enters every box: always the slot visited last, then the leaf's last triangle.
+    uint32_t ref = ps.root.ref;
+    while (ref != REF_NONE && !(ref & REF_LEAF)) {
+        const Node4& n = ps.nodes4[ref];
+        uint32_t last = REF_NONE;
+        for (int k = 0; k < 4; k++) if (n.c[k].ref != REF_NONE) last = n.c[k].ref;
+        ref = last;
+    }
+    ps.last_tri = ref == REF_NONE ? REF_NONE : (ref & REF_MASK) + ((ref & REF_PAIR) ? 1u : 0u);
     return 0;
 }
 

@@ -27,6 +27,7 @@ struct PackedScene {
     std::vector<TriShade> shade;
     std::vector<TriOrigin> origin;
     int max_depth = 0;               // deepest chain of inner nodes below the scene root (= stack slots needed)
+    uint32_t last_tri = REF_NONE;    // packed index of the triangle a walk that enters every box tests last
 };
 
 int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out);

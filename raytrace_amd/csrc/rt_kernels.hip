@@ -805,6 +805,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->dev.tex = (const TexDev*)ctx->d_tex;
     ctx->dev.texels = (const uint32_t*)ctx->d_texels;
     ctx->dev.n_materials = n_materials;
+    ctx->dev.last_tri = ps.last_tri;
     ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
     ctx->stats[0] = n_packed_tris;
     ctx->stats[1] = ps.nodes4.size();

@@ -101,6 +101,8 @@ def test_closest_hit_edge_cases(gpu_ctx):
         [0, 0, 5, 1, 0, 0], [0, 0, 5, 0, -1, 0],
         [0, 0, 5, 0, 0, 0],         # zero direction: every inverse is inf, every product NaN
         [0, 0, 5, np.nan, 0, 1],    # NaN direction
+        [0, 0, 5, np.nan, np.nan, np.nan],   # all-NaN direction: every box entered, every triangle 'accepted', the last one tested wins
+        [np.nan, 0, 5, np.nan, np.nan, np.nan],
         [1e30, 0, 0, -1, 0, 0],     # far outside
         [0, 0, 5, 1e-30, 1e-30, -1],
         [0, 0, 5, -0.0, 0.0, -1],   # signed zeros flip the slab order
@@ -146,6 +148,11 @@ def test_closest_hit_bit_exact_benchmark_scenes(gpu_ctx, name, kw):
     params = orc.make_params(p.cfg, SEED, 4)
     hit = p.check_hits(orc.primary_rays(params, 0))
     assert (hit >= 0).mean() > 0.3
+    # degenerate rays in a many-object scene: zero direction (nothing can be hit) and all-NaN direction (the last
+    # triangle upstream's walk tests wins) are answered without the walk and must still match the full walk
+    o = np.array(p.cfg.camera_pos, dtype=np.float32)
+    odd = np.array([[*o, 0, 0, 0], [*o, np.nan, np.nan, np.nan], [*o, -0.0, 0.0, -0.0]], dtype=np.float32)
+    p.check_hits(odd)
 
 
 @pytest.mark.parametrize("name,kw,spp,batch", [
