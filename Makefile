@@ -12,7 +12,7 @@ LIB := raytrace_amd/librtcore.so
 HOST     := raytrace_amd/host
 HOSTCXX  ?= g++
 HOSTCXXFLAGS := -std=c++17 -O2 -ffp-contract=off -Wall -Wextra -Iinclude -I$(HOST)
-HOST_OBJS := $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/scene_loader.o $(HOST)/worker.o $(HOST)/http_server.o
+HOST_OBJS := $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o $(HOST)/scene_loader.o $(HOST)/worker.o $(HOST)/http_server.o
 BINS     := bin/main bin/server bin/obj_dump bin/scene_dump bin/png_tool
 RPATH    := -Wl,-rpath,'$$ORIGIN/../raytrace_amd'
 
@@ -35,13 +35,13 @@ bin/obj_dump: tools/host/obj_dump.cpp $(HOST)/obj_model.o
 	@mkdir -p bin
 	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $^
 
-bin/png_tool: tools/host/png_tool.cpp $(HOST)/image_io.o
+bin/png_tool: tools/host/png_tool.cpp $(HOST)/image_io.o $(HOST)/jpeg_decode.o
 	@mkdir -p bin
 	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ $^ -lz
 
-bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(LIB)
+bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o $(LIB)
 	@mkdir -p bin
-	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o -Lraytrace_amd -lrtcore -lz $(RPATH)
+	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o -Lraytrace_amd -lrtcore -lz $(RPATH)
 
 $(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

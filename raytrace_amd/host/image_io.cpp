@@ -1,4 +1,4 @@
-// image_io.cpp -- see image_io.h.  PNG per the PNG specification (ISO/IEC 15948): chunks with CRC-32, one zlib
+// image_io.cpp -- see image_io.h.  JPEG lives in jpeg_decode.cpp.  PNG per the PNG specification (ISO/IEC 15948): chunks with CRC-32, one zlib
 // stream over the IDAT chunks, per-row filters 0-4.
 #include "image_io.h"
 
@@ -196,7 +196,7 @@ bool read_image(const std::string& path, Image8& out, std::string& error) {
     if (!read_file(path, file)) { error = "cannot read " + path; return false; }
     if (file.size() >= 8 && !std::memcmp(file.data(), kPngSignature, 8)) return decode_png(file, out, error);
     if (file.size() >= 8 && file[0] == 'P' && (file[1] == '6' || file[1] == '5')) return decode_pnm(file, out, error);
-    if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8) { error = "JPEG is not decoded here: convert " + path + " to PNG"; return false; }
+    if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8) return decode_jpeg(file, out, error);
     error = "unknown image format: " + path;
     return false;
 }

@@ -1,10 +1,10 @@
-// image_io.h -- image files without OpenCV: PNG (zlib) and binary PPM/PGM.
+// image_io.h -- image files without OpenCV: PNG (zlib), JPEG and binary PPM/PGM.
 //
 // Upstream decodes textures with cv::imread(IMREAD_COLOR) and writes frames with cv::imwrite
 // (csrc/sceneloader.cpp:224, csrc/worker.cpp:42).  Here: a PNG reader for every non-interlaced colour
 // type and bit depth (reduced to 8-bit RGB the way IMREAD_COLOR does: alpha dropped, grey replicated,
-// 16-bit samples keep their high byte), a binary PPM/PGM reader, and an 8-bit RGB PNG writer.
-// JPEG is not decoded: convert such textures to PNG.
+// 16-bit samples keep their high byte), a JPEG reader (jpeg_decode.cpp), a binary PPM/PGM reader, and an
+// 8-bit RGB PNG writer.
 #ifndef RT_IMAGE_IO_H
 #define RT_IMAGE_IO_H
 
@@ -19,7 +19,8 @@ struct Image8 {
     std::vector<uint8_t> rgb;      // 3 bytes per pixel, rows top to bottom
 };
 
-bool read_image(const std::string& path, Image8& out, std::string& error);       // PNG, PPM (P6) or PGM (P5) by signature
+bool read_image(const std::string& path, Image8& out, std::string& error);       // PNG, JPEG, PPM (P6) or PGM (P5) by signature
+bool decode_jpeg(const std::vector<uint8_t>& file, Image8& out, std::string& error);
 bool write_png_rgb8(const std::string& path, int width, int height, const uint8_t* rgb, std::string& error);
 
 // cv::Mat::convertTo(CV_8UC3, 255.0f) on one float: v * 255 in binary32, round half to even, saturate to 0..255;
