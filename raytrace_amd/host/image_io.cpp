@@ -1,5 +1,5 @@
 // image_io.cpp -- see image_io.h.  JPEG lives in jpeg_decode.cpp.  PNG per the PNG specification (ISO/IEC 15948): chunks with CRC-32, one zlib
-// stream over the IDAT chunks, per-row filters 0-4.
+// stream over the IDAT chunks, per-row filters 0-4, Adam7 interlacing.
 #include "image_io.h"
 
 #include <zlib.h>
@@ -76,7 +76,7 @@ bool decode_png(const std::vector<uint8_t>& file, Image8& out, std::string& erro
         pos += 12 + size_t(n);
     }
     if (colour < 0 || width == 0 || height == 0 || width > 65535u || height > 65535u) { error = "PNG: missing or implausible IHDR"; return false; }
-    if (interlace != 0) { error = "PNG: interlaced files are not supported"; return false; }
+    if (interlace > 1) { error = "PNG: unknown interlace method"; return false; }
     int channels;
     switch (colour) {
     case 0: channels = 1; break;
@@ -92,66 +92,87 @@ bool decode_png(const std::vector<uint8_t>& file, Image8& out, std::string& erro
     if (!depth_ok) { error = "PNG: bit depth not allowed for the colour type"; return false; }
     if (colour == 3 && palette.size() < 3) { error = "PNG: palette image without PLTE"; return false; }
     const size_t bits_per_pixel = size_t(channels) * size_t(depth);
-    const size_t stride = (size_t(width) * bits_per_pixel + 7) / 8;
     const size_t bpp = bits_per_pixel >= 8 ? bits_per_pixel / 8 : 1;      // filter distance in bytes
-    std::vector<uint8_t> raw((stride + 1) * size_t(height));
+    // the passes of the file: the whole image, or the seven Adam7 sub-images (x0, y0, dx, dy), each filtered on its own
+    struct Pass { size_t x0, y0, dx, dy, w, h, stride; };
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    std::vector<Pass> passes;
+    size_t total = 0;
+    for (int k = 0; k < (interlace ? 7 : 1); k++) {
+        Pass ps;
+        if (interlace) { ps.x0 = size_t(adam7[k][0]); ps.y0 = size_t(adam7[k][1]); ps.dx = size_t(adam7[k][2]); ps.dy = size_t(adam7[k][3]); }
+        else { ps.x0 = ps.y0 = 0; ps.dx = ps.dy = 1; }
+        ps.w = (size_t(width) + ps.dx - 1 - ps.x0) / ps.dx;
+        ps.h = (size_t(height) + ps.dy - 1 - ps.y0) / ps.dy;
+        if (size_t(width) <= ps.x0 || size_t(height) <= ps.y0) ps.w = ps.h = 0;
+        ps.stride = (ps.w * bits_per_pixel + 7) / 8;
+        if (ps.w == 0 || ps.h == 0) continue;                            // an empty pass has no bytes at all
+        total += (ps.stride + 1) * ps.h;
+        passes.push_back(ps);
+    }
+    std::vector<uint8_t> raw(total);
     uLongf raw_len = uLongf(raw.size());
     if (idat.empty() || uncompress(raw.data(), &raw_len, idat.data(), uLong(idat.size())) != Z_OK || raw_len != raw.size()) {
         error = "PNG: image data does not inflate to the declared size";
         return false;
     }
-    // undo the row filters in place
-    std::vector<uint8_t> zero(stride, 0);
-    for (size_t y = 0; y < height; y++) {
-        uint8_t* row = &raw[y * (stride + 1) + 1];
-        const uint8_t* up = y ? &raw[(y - 1) * (stride + 1) + 1] : zero.data();
-        const int filter = raw[y * (stride + 1)];
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? row[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-            int pred;
-            switch (filter) {
-            case 0: pred = 0; break;
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) >> 1; break;
-            case 4: pred = paeth(a, b, c); break;
-            default: error = "PNG: unknown row filter"; return false;
-            }
-            row[i] = uint8_t(row[i] + pred);
-        }
-    }
     out.width = int(width); out.height = int(height);
     out.rgb.resize(size_t(width) * height * 3);
-    for (size_t y = 0; y < height; y++) {
-        const uint8_t* row = &raw[y * (stride + 1) + 1];
-        uint8_t* dst = &out.rgb[y * size_t(width) * 3];
-        for (size_t x = 0; x < width; x++) {
-            uint8_t r, g, b;
-            if (depth < 8) {                     // grey or palette index packed high bit first
-                const size_t bit = x * size_t(depth);
-                const int v = (row[bit >> 3] >> (8 - depth - int(bit & 7))) & ((1 << depth) - 1);
-                if (colour == 3) {
-                    const size_t k = size_t(v) * 3;
-                    if (k + 2 < palette.size()) { r = palette[k]; g = palette[k + 1]; b = palette[k + 2]; }
-                    else { r = g = b = 0; }
-                } else {
-                    r = g = b = uint8_t(v * 255 / ((1 << depth) - 1));
+    size_t base = 0;
+    for (const Pass& ps : passes) {
+        // undo the row filters in place
+        std::vector<uint8_t> zero(ps.stride, 0);
+        for (size_t y = 0; y < ps.h; y++) {
+            uint8_t* row = &raw[base + y * (ps.stride + 1) + 1];
+            const uint8_t* up = y ? &raw[base + (y - 1) * (ps.stride + 1) + 1] : zero.data();
+            const int filter = raw[base + y * (ps.stride + 1)];
+            for (size_t i = 0; i < ps.stride; i++) {
+                const int a = i >= bpp ? row[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+                int pred;
+                switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: pred = paeth(a, b, c); break;
+                default: error = "PNG: unknown row filter"; return false;
                 }
-            } else {
-                const size_t step = size_t(depth) / 8;            // 16-bit samples: the high byte is kept
-                const uint8_t* px = row + x * size_t(channels) * step;
-                if (colour == 3) {
-                    const size_t k = size_t(px[0]) * 3;
-                    if (k + 2 < palette.size()) { r = palette[k]; g = palette[k + 1]; b = palette[k + 2]; }
-                    else { r = g = b = 0; }
-                } else if (colour == 0 || colour == 4) {
-                    r = g = b = px[0];
-                } else {
-                    r = px[0]; g = px[step]; b = px[2 * step];
-                }
+                row[i] = uint8_t(row[i] + pred);
             }
-            dst[3 * x] = r; dst[3 * x + 1] = g; dst[3 * x + 2] = b;
         }
+        for (size_t y = 0; y < ps.h; y++) {
+            const uint8_t* row = &raw[base + y * (ps.stride + 1) + 1];
+            uint8_t* dst = &out.rgb[(ps.y0 + y * ps.dy) * size_t(width) * 3];
+            for (size_t x = 0; x < ps.w; x++) {
+                uint8_t r, g, b;
+                if (depth < 8) {                     // grey or palette index packed high bit first
+                    const size_t bit = x * size_t(depth);
+                    const int v = (row[bit >> 3] >> (8 - depth - int(bit & 7))) & ((1 << depth) - 1);
+                    if (colour == 3) {
+                        const size_t k = size_t(v) * 3;
+                        if (k + 2 < palette.size()) { r = palette[k]; g = palette[k + 1]; b = palette[k + 2]; }
+                        else { r = g = b = 0; }
+                    } else {
+                        r = g = b = uint8_t(v * 255 / ((1 << depth) - 1));
+                    }
+                } else {
+                    const size_t step = size_t(depth) / 8;            // 16-bit samples: the high byte is kept
+                    const uint8_t* px = row + x * size_t(channels) * step;
+                    if (colour == 3) {
+                        const size_t k = size_t(px[0]) * 3;
+                        if (k + 2 < palette.size()) { r = palette[k]; g = palette[k + 1]; b = palette[k + 2]; }
+                        else { r = g = b = 0; }
+                    } else if (colour == 0 || colour == 4) {
+                        r = g = b = px[0];
+                    } else {
+                        r = px[0]; g = px[step]; b = px[2 * step];
+                    }
+                }
+                uint8_t* o = dst + (ps.x0 + x * ps.dx) * 3;
+                o[0] = r; o[1] = g; o[2] = b;
+            }
+        }
+        base += (ps.stride + 1) * ps.h;
     }
     return true;
 }

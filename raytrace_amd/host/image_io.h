@@ -1,8 +1,8 @@
 // image_io.h -- image files without OpenCV: PNG (zlib), JPEG and binary PPM/PGM.
 //
 // Upstream decodes textures with cv::imread(IMREAD_COLOR) and writes frames with cv::imwrite
-// (csrc/sceneloader.cpp:224, csrc/worker.cpp:42).  Here: a PNG reader for every non-interlaced colour
-// type and bit depth (reduced to 8-bit RGB the way IMREAD_COLOR does: alpha dropped, grey replicated,
+// (csrc/sceneloader.cpp:224, csrc/worker.cpp:42).  Here: a PNG reader for every colour type and bit
+// depth, interlaced or not (reduced to 8-bit RGB the way IMREAD_COLOR does: alpha dropped, grey replicated,
 // 16-bit samples keep their high byte), a JPEG reader (jpeg_decode.cpp), a binary PPM/PGM reader, and an
 // 8-bit RGB PNG writer.
 #ifndef RT_IMAGE_IO_H

@@ -28,12 +28,10 @@ def run(*cmd):
 # ---------------------------------------------------------------------------------------------------------------
 # image files
 # ---------------------------------------------------------------------------------------------------------------
-def png_bytes(width, height, depth, colour, rows, palette=None, filters=None):
-    """A PNG from raw sample rows (bytes per row already packed), with the given filter type per row."""
-    def chunk(kind, data):
-        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
-    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
-    bpp = max(1, channels * depth // 8)
+def filtered(rows, bpp, filters=None):
+    """Scanlines with a filter type byte in front of each, the way one image (or one interlace pass) is stored."""
+    if not rows:
+        return b""
     raw, prev = b"", bytes(len(rows[0]))
     for y, row in enumerate(rows):
         f = filters[y % len(filters)] if filters else 0
@@ -57,12 +55,47 @@ def png_bytes(width, height, depth, colour, rows, palette=None, filters=None):
             out[i] = (row[i] - pred) & 255
         raw += bytes([f]) + bytes(out)
         prev = row
-    body = chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, colour, 0, 0, 0))
+    return raw
+
+
+def png_file(width, height, depth, colour, raw, palette=None, interlace=0):
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, colour, 0, 0, interlace))
     if palette is not None:
         body += chunk(b"PLTE", bytes(palette))
     z = zlib.compress(raw)
     body += chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:])       # split stream: two IDAT chunks
     return b"\x89PNG\r\n\x1a\n" + body + chunk(b"IEND", b"")
+
+
+def png_bytes(width, height, depth, colour, rows, palette=None, filters=None):
+    """A PNG from raw sample rows (bytes per row already packed), with the given filter type per row."""
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    return png_file(width, height, depth, colour, filtered(rows, max(1, channels * depth // 8), filters), palette)
+
+
+def pack_row(samples, depth):
+    """One scanline from a flat list of samples: big-endian 16-bit, bytes, or sub-byte samples packed high bit first."""
+    if depth == 16:
+        return b"".join(struct.pack(">H", int(v)) for v in samples)
+    if depth == 8:
+        return bytes(int(v) for v in samples)
+    per = 8 // depth
+    vals = [int(v) for v in samples] + [0] * (-len(samples) % per)
+    return bytes(sum(vals[i + k] << (8 - depth * (k + 1)) for k in range(per)) for i in range(0, len(vals), per))
+
+
+def png_adam7(samples, depth, colour, palette=None, filters=None):
+    """An interlaced PNG from samples[h, w, channels]: seven sub-images, each with its own scanlines and filters."""
+    h, w, channels = samples.shape
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        raw += filtered([pack_row(sub[y].reshape(-1), depth) for y in range(sub.shape[0])], max(1, channels * depth // 8), filters)
+    return png_file(w, h, depth, colour, raw, palette, interlace=1)
 
 
 def decode(path, tmp_path):
@@ -122,6 +155,33 @@ def test_png_decoder_colour_types_depths_and_filters(tmp_path):
         open(p, "wb").write(png_bytes(w, h, depth, 0, rows))
         got, _ = decode(p, tmp_path)
         assert np.array_equal(got[:, :, 0], (v * 255 // ((1 << depth) - 1)).astype(np.uint8))
+
+
+def test_png_decoder_adam7(tmp_path):
+    """Interlaced files: every size from 1x1 to beyond one 8x8 tile, so that passes come out empty, partial and full."""
+    rng = np.random.RandomState(6)
+    p = str(tmp_path / "i.png")
+    for w, h in [(1, 1), (2, 1), (1, 3), (3, 2), (4, 4), (5, 7), (8, 8), (9, 9), (13, 17), (33, 5)]:
+        rgb = rng.randint(0, 256, size=(h, w, 3))
+        open(p, "wb").write(png_adam7(rgb, 8, 2, filters=[0, 1, 2, 3, 4]))
+        got, err = decode(p, tmp_path)
+        assert got is not None, err
+        assert np.array_equal(got, rgb.astype(np.uint8)), (w, h)
+    w, h = 21, 11
+    rgba16 = rng.randint(0, 65536, size=(h, w, 4))
+    open(p, "wb").write(png_adam7(rgba16, 16, 6, filters=[4]))
+    got, _ = decode(p, tmp_path)
+    assert np.array_equal(got, (rgba16[:, :, :3] >> 8).astype(np.uint8))
+    for depth in (1, 2, 4):                                   # sub-byte samples: each pass row is padded to a byte on its own
+        v = rng.randint(0, 1 << depth, size=(h, w, 1))
+        open(p, "wb").write(png_adam7(v, depth, 0, filters=[1, 2]))
+        got, _ = decode(p, tmp_path)
+        assert np.array_equal(got[:, :, 0], (v[:, :, 0] * 255 // ((1 << depth) - 1)).astype(np.uint8)), depth
+    pal = rng.randint(0, 256, size=(4, 3)).astype(np.uint8)
+    idx = rng.randint(0, 4, size=(h, w, 1))
+    open(p, "wb").write(png_adam7(idx, 2, 3, palette=pal.tobytes()))
+    got, _ = decode(p, tmp_path)
+    assert np.array_equal(got, pal[idx[:, :, 0]])
 
 
 def test_png_decoder_rejects_what_it_cannot_read(tmp_path):
