@@ -114,10 +114,13 @@ def main():
     cfg = asm.config
     if args.depth:
         cfg.max_depth = args.depth
+    t_assemble = time.time() - t0
     objs = scene.finalize(asm, progress=(lambda i, n: log(f"  object {i}/{n} transformed, BVH built") if (i % 8 == 0 or i == n) and rank == 0 else None))
-    t_build = time.time() - t0
+    t_build = time.time() - t0 - t_assemble
     ctx = capi.Context(device_index)
+    t1 = time.time()
     ctx.upload_scene(objs, asm.materials, asm.textures)
+    t_upload = time.time() - t1
     stats = ctx.scene_stats()
     if args.chunk:
         ctx.set_option(capi.OPT_CHUNK, args.chunk)
@@ -146,7 +149,8 @@ def main():
     npix = cfg.width * cfg.height
     if rank == 0:
         log(f"scene {args.scene}: {stats['triangles']} triangles, {stats['objects']} objects, "
-            f"{stats['device_bytes'] / 1e6:.1f} MB packed, built in {t_build:.1f}s")
+            f"{stats['device_bytes'] / 1e6:.1f} MB packed, models generated in {t_assemble:.1f}s, "
+            f"transform + BVH build {t_build:.1f}s ({os.environ.get('RT_HOST_THREADS', 'up to 16')} threads), re-pack + upload {t_upload:.1f}s")
 
     accum = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
     staging = torch.zeros_like(accum) if world > 1 else None

@@ -6,7 +6,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace rtc {
 
@@ -39,17 +43,48 @@ inline void store_box(rt_bvh_node& n, const Box& b) {
     n.box_max = rt_float3{b.hi.x, b.hi.y, b.hi.z};
 }
 
+// Worker threads for the host halves: RT_HOST_THREADS, else the machine's count capped at 16.
+int host_threads() {
+    if (const char* e = std::getenv("RT_HOST_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return v > 256 ? 256 : v;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 1 : (hw > 16 ? 16 : int(hw));
+}
+
+// Nodes of the subtree over n triangles.  The split point depends on the count alone (the lower part takes
+// (n-1)/2 + 1 triangles), so the shape of the tree, and with it the index of every node in the post-order array,
+// is known before any triangle is looked at.
+int subtree_nodes(int n) {
+    if (n <= 2) return 1;
+    const int lower = (n - 1) / 2 + 1, upper = n - lower;
+    const int a = subtree_nodes(lower);
+    return a + (upper == lower ? a : subtree_nodes(upper)) + 1;
+}
+
 // Median-split builder.  The permutation is carried by an index array; the
 // comparator reads the centroid table, so std::nth_element sees exactly the
 // comparison outcomes upstream's struct-array version sees (csrc/bvh.cpp:61-64)
 // and leaves the same arrangement behind -- which decides the leaf pairing.
+// Every subtree owns a range of the index array and a range of the output array, so subtrees are built by
+// different threads without changing a byte of the result.
 struct Builder {
     const rt_triangle* tris;
     std::vector<V3> centroid;
     std::vector<int> order;
-    std::vector<rt_bvh_node>* out;
+    rt_bvh_node* out;
 
-    void emit_leaf(int first, int last) {
+    struct Job { int first, last, base; };
+    struct Top { int self, left, right; };               // nodes above the jobs, in creation order (parents first)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Job> jobs;
+    std::vector<Top> tops;
+    int pending = 0;                                     // jobs queued or running
+    int grain = 1 << 30;                                 // ranges up to this many triangles are built by one thread
+
+    void emit_leaf(int first, int last, int at) {
         rt_bvh_node n;
         std::memset(&n, 0, sizeof(n));
         n.is_leaf = 1;
@@ -61,11 +96,11 @@ struct Builder {
             grow(b, box_of(tris[n.right]));
         }
         store_box(n, b);
-        out->push_back(n);
+        out[at] = n;
     }
 
-    void split(int first, int last) {   // inclusive range, csrc/bvh.cpp:29-75
-        if (first + 1 >= last) { emit_leaf(first, last); return; }
+    // Partition [first, last] at the median of the widest centroid axis; returns the centroid box.
+    Box partition(int first, int last, int mid) {
         Box cb{V3{INFINITY, INFINITY, INFINITY}, V3{-INFINITY, -INFINITY, -INFINITY}};
         for (int i = first; i <= last; i++) grow(cb, centroid[order[i]]);
         int axis = 0;
@@ -74,23 +109,77 @@ struct Builder {
         if (w > widest) { axis = 1; widest = w; }
         w = cb.hi.z - cb.lo.z;
         if (w > widest) axis = 2;
-        const int mid = (first + last) / 2;
         const V3* c = centroid.data();
         std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + last + 1,
                          [c, axis](int a, int b) { return comp(c[a], axis) < comp(c[b], axis); });
-        split(first, mid);
-        const int left = (int)out->size() - 1;
-        split(mid + 1, last);
-        const int right = (int)out->size() - 1;
-        grow(cb, node_box((*out)[left]));
-        grow(cb, node_box((*out)[right]));
+        return cb;
+    }
+
+    void finish_inner(int self, int left, int right, Box cb) {
+        grow(cb, node_box(out[left]));
+        grow(cb, node_box(out[right]));
         rt_bvh_node n;
         std::memset(&n, 0, sizeof(n));
         n.is_leaf = 0;
         n.left = left;
         n.right = right;
         store_box(n, cb);
-        out->push_back(n);
+        out[self] = n;
+    }
+
+    // inclusive range, csrc/bvh.cpp:29-75; the subtree's nodes go to out[base...], its root last; returns the root
+    int split(int first, int last, int base) {
+        if (first + 1 >= last) { emit_leaf(first, last, base); return base; }
+        const int mid = (first + last) / 2;
+        const Box cb = partition(first, last, mid);
+        const int left = split(first, mid, base);
+        const int right = split(mid + 1, last, left + 1);
+        finish_inner(right + 1, left, right, cb);
+        return right + 1;
+    }
+
+    // One queued range: small ones are built whole, large ones are partitioned and handed on as two ranges.  The
+    // box of a handed-on node holds its centroid box until finish_tops() adds the boxes of its children.
+    void run(const Job& j) {
+        const int n = j.last - j.first + 1;
+        if (n <= grain) { split(j.first, j.last, j.base); return; }
+        const int mid = (j.first + j.last) / 2;
+        const Box cb = partition(j.first, j.last, mid);
+        const int left = j.base + subtree_nodes(mid - j.first + 1) - 1;
+        const int right = left + subtree_nodes(j.last - mid);
+        rt_bvh_node nd;
+        std::memset(&nd, 0, sizeof(nd));
+        store_box(nd, cb);
+        out[right + 1] = nd;
+        std::lock_guard<std::mutex> lock(mu);
+        tops.push_back(Top{right + 1, left, right});
+        jobs.push_back(Job{j.first, mid, j.base});
+        jobs.push_back(Job{mid + 1, j.last, left + 1});
+        pending += 2;
+        cv.notify_all();
+    }
+
+    void worker() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [this] { return !jobs.empty() || pending == 0; });
+                if (jobs.empty()) return;
+                j = jobs.back();
+                jobs.pop_back();
+            }
+            run(j);
+            std::lock_guard<std::mutex> lock(mu);
+            if (--pending == 0) cv.notify_all();
+        }
+    }
+
+    void finish_tops() {                                  // children were created after their parents: walk backwards
+        for (size_t i = tops.size(); i-- > 0;) {
+            const Top& t = tops[i];
+            finish_inner(t.self, t.left, t.right, node_box(out[t.self]));
+        }
     }
 };
 
@@ -98,10 +187,10 @@ struct Builder {
 
 int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out) {
     out.clear();
-    out.reserve((size_t)n + 1);
+    out.resize((size_t)subtree_nodes(n));
     Builder b;
     b.tris = tris;
-    b.out = &out;
+    b.out = out.data();
     b.centroid.resize(n);
     b.order.resize(n);
     const float third = 1.f / 3.0f;   // upstream's float3 `/ 3.0f` multiplies by the reciprocal (common.cuh:148-153)
@@ -110,7 +199,19 @@ int build_bvh(const rt_triangle* tris, int n, std::vector<rt_bvh_node>& out) {
         b.centroid[i] = V3{((a.x + bb.x) + c.x) * third, ((a.y + bb.y) + c.y) * third, ((a.z + bb.z) + c.z) * third};
         b.order[i] = i;
     }
-    b.split(0, n - 1);
+    const int threads = n < (1 << 16) ? 1 : host_threads();
+    if (threads <= 1) {
+        b.split(0, n - 1, 0);
+    } else {
+        b.grain = std::max(1 << 13, n / (threads * 8));
+        b.jobs.push_back(Builder::Job{0, n - 1, 0});
+        b.pending = 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back([&b] { b.worker(); });
+        b.worker();
+        for (std::thread& t : pool) t.join();
+        b.finish_tops();
+    }
     return (int)out.size();
 }
 
@@ -131,14 +232,22 @@ void apply_transform(const rt_transform& xf, rt_triangle* tris, int n) {
         v.y = m[3] * x + m[4] * y + m[5] * z;
         v.z = m[6] * x + m[7] * y + m[8] * z;
     };
-    for (int t = 0; t < n; t++)
-        for (int k = 0; k < 3; k++) {
-            rt_vertex& v = tris[t].v[k];
-            v.position.x *= xf.scale.x; v.position.y *= xf.scale.y; v.position.z *= xf.scale.z;
-            rot(v.position);
-            v.position.x += xf.translation.x; v.position.y += xf.translation.y; v.position.z += xf.translation.z;
-            rot(v.normal);
-        }
+    auto range = [&](int first, int last) {
+        for (int t = first; t < last; t++)
+            for (int k = 0; k < 3; k++) {
+                rt_vertex& v = tris[t].v[k];
+                v.position.x *= xf.scale.x; v.position.y *= xf.scale.y; v.position.z *= xf.scale.z;
+                rot(v.position);
+                v.position.x += xf.translation.x; v.position.y += xf.translation.y; v.position.z += xf.translation.z;
+                rot(v.normal);
+            }
+    };
+    const int threads = n < (1 << 16) ? 1 : host_threads();
+    if (threads <= 1) { range(0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back(range, int(int64_t(n) * t / threads), int(int64_t(n) * (t + 1) / threads));
+    for (std::thread& t : pool) t.join();
 }
 
 CameraFrame camera_frame(int width, int height, const float pos[3], const float dir_in[3], const float up_in[3], float fov) {
@@ -174,11 +283,15 @@ CameraFrame camera_frame(int width, int height, const float pos[3], const float 
 // ---------------------------------------------------------------------------
 namespace {
 
+// Emits one object's records.  The expanded size of every subtree (inner nodes, triangles) is counted first, so each
+// subtree owns a range of the node array and of the triangle arrays; subtrees near the root go to threads of their own.
 struct Packer {
     PackedScene* ps;
     const rt_object* obj;
     int obj_index;
-    int max_depth;
+    const uint32_t* inner_below;     // per upstream node: inner nodes of its subtree, itself included
+    const uint32_t* tris_below;      // per upstream node: triangles of its subtree
+    int spawn_depth;                 // subtrees above this depth are split over two threads
 
     static void put_box(ChildRec& c, const rt_bvh_node& n) {
         c.bmin[0] = n.box_min.x; c.bmin[1] = n.box_min.y; c.bmin[2] = n.box_min.z;
@@ -186,7 +299,7 @@ struct Packer {
         c.aux = 0;
     }
 
-    uint32_t add_triangle(int ti) {
+    void put_triangle(int ti, uint32_t at) const {
         const rt_triangle& t = obj->triangles[ti];
         TriIsect r;
         std::memset(&r, 0, sizeof(r));
@@ -203,27 +316,37 @@ struct Packer {
             uv[0] = t.v[k].texcoord[0]; uv[1] = t.v[k].texcoord[1];
         }
         s.material_id = t.material_id;
-        const uint32_t p = (uint32_t)ps->isect.size();
-        ps->isect.push_back(r);
-        ps->shade.push_back(s);
-        ps->origin.push_back(TriOrigin{obj_index, ti});
-        return p;
+        ps->isect[at] = r;
+        ps->shade[at] = s;
+        ps->origin[at] = TriOrigin{obj_index, ti};
     }
 
-    // Returns the reference for upstream node `ni`, emitting packed records below it.
-    uint32_t emit(int ni, int depth) {
+    // Returns the reference for upstream node `ni`; its inner nodes go to nodes[node_at...], its triangles to
+    // [tri_at...].  `deepest` receives the largest depth of an inner node below.
+    uint32_t emit(int ni, int depth, uint32_t node_at, uint32_t tri_at, int& deepest) const {
         const rt_bvh_node& n = obj->bvh[ni];
         if (n.is_leaf) {
-            uint32_t ref = REF_LEAF | add_triangle(n.left);
-            if (n.right >= 0) { add_triangle(n.right); ref |= REF_PAIR; }
+            uint32_t ref = REF_LEAF | tri_at;
+            put_triangle(n.left, tri_at);
+            if (n.right >= 0) { put_triangle(n.right, tri_at + 1); ref |= REF_PAIR; }
             return ref;
         }
-        if (depth + 1 > max_depth) max_depth = depth + 1;
-        const uint32_t me = (uint32_t)ps->nodes.size();
-        ps->nodes.emplace_back();
+        if (depth + 1 > deepest) deepest = depth + 1;
+        const uint32_t me = node_at;
         // children are emitted right-first so that memory order follows upstream's visiting order
-        const uint32_t rr = emit(n.right, depth + 1);
-        const uint32_t lr = emit(n.left, depth + 1);
+        const uint32_t right_nodes = me + 1, left_nodes = right_nodes + inner_below[n.right];
+        const uint32_t right_tris = tri_at, left_tris = tri_at + tris_below[n.right];
+        uint32_t rr, lr;
+        if (depth < spawn_depth && tris_below[ni] >= (1u << 15)) {
+            int deep_r = 0, deep_l = 0;
+            std::thread other([&] { rr = emit(n.right, depth + 1, right_nodes, right_tris, deep_r); });
+            lr = emit(n.left, depth + 1, left_nodes, left_tris, deep_l);
+            other.join();
+            deepest = std::max(deepest, std::max(deep_r, deep_l));
+        } else {
+            rr = emit(n.right, depth + 1, right_nodes, right_tris, deepest);
+            lr = emit(n.left, depth + 1, left_nodes, left_tris, deepest);
+        }
         Node64& out = ps->nodes[me];
         put_box(out.c[0], obj->bvh[n.left]);
         out.c[0].ref = lr;
@@ -327,22 +450,22 @@ static void renumber_breadth_first(PackedScene& ps) {
 
 int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
     ps = PackedScene();
-    size_t total_tris = 0;
     for (int i = 0; i < n_objects; i++) {
         if (!objects[i].triangles || !objects[i].bvh || objects[i].n_triangles <= 0 || objects[i].n_bvh_nodes <= 0) {
             err = "object " + std::to_string(i) + ": empty triangle or node array";
             return -1;
         }
-        total_tris += (size_t)objects[i].n_triangles;
     }
-    if (total_tris > (size_t)REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
-    ps.isect.reserve(total_tris);
-    ps.shade.reserve(total_tris);
-    ps.origin.reserve(total_tris);
-    ps.top.resize(n_objects);
+    // Per object: validate child indices (a bad index would otherwise read out of bounds), and count what each
+    // subtree expands to.  Children precede their parents in the array, so one forward pass does both.
+    std::vector<std::vector<uint32_t>> inner_below(n_objects), tris_below(n_objects);
+    uint64_t total_tris = 0, total_inner = 0;
     for (int i = 0; i < n_objects; i++) {
         const rt_object& o = objects[i];
-        // validate child indices before walking (a bad index would otherwise read out of bounds)
+        std::vector<uint32_t>& inner = inner_below[i];
+        std::vector<uint32_t>& tri = tris_below[i];
+        inner.resize(o.n_bvh_nodes);
+        tri.resize(o.n_bvh_nodes);
         for (int k = 0; k < o.n_bvh_nodes; k++) {
             const rt_bvh_node& n = o.bvh[k];
             const int lim = n.is_leaf ? o.n_triangles : o.n_bvh_nodes;
@@ -350,15 +473,40 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
                 err = "object " + std::to_string(i) + ": node " + std::to_string(k) + " has an invalid child index";
                 return -1;
             }
+            if (n.is_leaf) {
+                inner[k] = 0;
+                tri[k] = n.right >= 0 ? 2 : 1;
+            } else {
+                const uint64_t a = uint64_t(inner[n.left]) + inner[n.right] + 1, b = uint64_t(tri[n.left]) + tri[n.right];
+                if (a > REF_MASK || b > REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
+                inner[k] = uint32_t(a);
+                tri[k] = uint32_t(b);
+            }
         }
-        Packer p{&ps, &o, i, 0};
+        total_tris += tri[o.n_bvh_nodes - 1];
+        total_inner += inner[o.n_bvh_nodes - 1];
+    }
+    if (total_tris > (uint64_t)REF_MASK || total_inner > (uint64_t)REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
+    ps.isect.resize(total_tris);
+    ps.shade.resize(total_tris);
+    ps.origin.resize(total_tris);
+    ps.nodes.reserve(total_inner + (size_t)n_objects);
+    ps.nodes.resize(total_inner);
+    ps.top.resize(n_objects);
+    int spawn_depth = 0;
+    for (int t = host_threads(); t > 1; t >>= 1) spawn_depth++;
+    uint32_t node_at = 0, tri_at = 0;
+    for (int i = 0; i < n_objects; i++) {
+        const rt_object& o = objects[i];
+        const Packer p{&ps, &o, i, inner_below[i].data(), tris_below[i].data(), spawn_depth};
         const int root = o.n_bvh_nodes - 1;   // cuda/raytrace.cu:49
-        const size_t tris_before = ps.isect.size();
-        const uint32_t ref = p.emit(root, 0);
+        int deepest = 0;
+        const uint32_t ref = p.emit(root, 0, node_at, tri_at, deepest);
         Packer::put_box(ps.top[i], o.bvh[root]);
         ps.top[i].ref = ref;
-        if (p.max_depth > ps.max_depth) ps.max_depth = p.max_depth;
-        (void)tris_before;
+        if (deepest > ps.max_depth) ps.max_depth = deepest;
+        node_at += inner_below[i][root];
+        tri_at += tris_below[i][root];
     }
     // Object-level tree.  Upstream loops over the objects in ascending order and starts each
     // with a slab test of its root box (cuda/raytrace.cu:217-219, 49-55).  The same visiting order

@@ -56,6 +56,25 @@ def test_build_bvh_with_equal_centroids_and_degenerate_triangles():
     assert same_nodes(capi.build_bvh(grid), orc.build_bvh(grid))
 
 
+def test_threaded_host_halves_leave_the_same_bytes(monkeypatch):
+    """Above 65536 triangles the build and the vertex transform run on several threads (RT_HOST_THREADS, else up to
+    16): every subtree owns fixed ranges of the index and node arrays, so the thread count cannot change a byte."""
+    tris = _random_tris(150_001, 11)
+    tris["v"]["position"][::7, :, 1] = np.float32(3.0)          # equal keys here and there
+    results = []
+    for threads in ("1", "2", "5", "16"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        t = tris.copy()
+        capi.apply_transform(t, (2, 3, 0.5), (1, -2, 3), (10, 200, -33))
+        results.append((t, capi.build_bvh(t)))
+    for t, nodes in results[1:]:
+        assert same_triangles(t, results[0][0]) and same_nodes(nodes, results[0][1])
+    b = tris.copy()
+    orc.apply_transform(b, (2, 3, 0.5), (1, -2, 3), (10, 200, -33))
+    assert same_triangles(results[0][0], b)
+    assert same_nodes(results[-1][1], orc.build_bvh(b))
+
+
 def test_build_bvh_rejects_bad_arguments():
     lib = capi.load()
     nodes = np.zeros(4, dtype=capi.NODE_DTYPE)
