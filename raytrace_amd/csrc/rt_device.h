@@ -76,8 +76,10 @@ __device__ __forceinline__ void philox(uint32_t x0, uint32_t x1, uint32_t x2, ui
                                        uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a high and a low multiply
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ x1 ^ k0;
         const uint32_t n2 = hi0 ^ x3 ^ k1;
         x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
