@@ -323,3 +323,56 @@ def blob(n_tris, seed=1):
     rs = np.random.RandomState(seed)
     f = (int(rs.randint(3, 9)), int(rs.randint(3, 9)))
     return Model([_grid_surface(f"blob{seed}", _ellipsoid((0, 0, 0), (1.0, 0.8, 0.9), bumps=0.12, freq=f, phase=float(rs.rand())), n, n, -1)])
+
+
+def fitted(model, lo, hi):
+    """The model scaled and moved per axis so that its bounding box becomes [lo, hi]; normals and uvs stay as they are.
+    Lets one generator stand in for models of very different sizes (the upstream scene files carry the transforms of
+    the real models, so a stand-in has to occupy about the same model-space box)."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    allpos = np.concatenate([sh.pos.reshape(-1, 3) for sh in model.shapes]).astype(np.float64)
+    a, b = allpos.min(axis=0), allpos.max(axis=0)
+    k = (hi - lo) / np.where(b > a, b - a, 1.0)
+    shapes = []
+    for sh in model.shapes:
+        out = Shape(sh.name, (sh.pos.astype(np.float64) - a) * k + lo, sh.nrm, sh.uv, sh.mtl)
+        out.has_normals, out.has_uvs = sh.has_normals, sh.has_uvs
+        shapes.append(out)
+    return Model(shapes, model.mtls)
+
+
+def room(detail=1.0, tex_size=256):
+    """Dining-room stand-in, y up, about 1400 x 300 x 1700 units with the corner at the origin and z running negative:
+    walls seen from inside, a table, seats, a mirror, a glass vase and a small lamp; 8 MTL records, two textured."""
+    def d(n):
+        return max(4, int(round(n * detail ** 0.5)))
+    mtls = [
+        mtl("plaster", 1, Kd=(0.82, 0.8, 0.76)),
+        mtl("floor", 1, Kd=(0.6, 0.5, 0.4), map_Kd=texture("checker", tex_size, 11)),
+        mtl("wood", 1, Kd=(0.45, 0.3, 0.18), map_Kd=texture("noise", tex_size, 12)),
+        mtl("fabric", 1, Kd=(0.3, 0.35, 0.6)),
+        mtl("steel", 2, Kd=(0.8, 0.8, 0.82)),
+        mtl("mirror", 5, Kd=(0.95, 0.95, 0.95)),
+        mtl("vase", 4, Kd=(0.8, 1.0, 0.9), Ni=1.5, d=0.3),
+        mtl("bulb", 3, Ke=(1.0, 0.9, 0.7)),
+    ]
+    PLASTER, FLOOR, WOOD, FABRIC, STEEL, MIRROR, VASE, BULB = range(8)
+    shapes = []
+    # the six faces of the room as thin slabs (each its own shape, as a modelling tool would export them)
+    cx, cy, cz = 700.0, 150.0, -850.0
+    shapes.append(_grid_surface("floor", _slab((cx, -2.0, cz), (700.0, 2.0, 850.0)), d(60), d(60), FLOOR))
+    shapes.append(_grid_surface("ceiling", _slab((cx, 302.0, cz), (700.0, 2.0, 850.0)), d(40), d(40), PLASTER))
+    shapes.append(_grid_surface("wall_x0", _slab((-2.0, cy, cz), (2.0, 150.0, 850.0)), d(40), d(40), PLASTER))
+    shapes.append(_grid_surface("wall_x1", _slab((1402.0, cy, cz), (2.0, 150.0, 850.0)), d(40), d(40), PLASTER))
+    shapes.append(_grid_surface("wall_z0", _slab((cx, cy, 2.0), (700.0, 150.0, 2.0)), d(40), d(40), PLASTER))
+    shapes.append(_grid_surface("wall_z1", _slab((cx, cy, -1702.0), (700.0, 150.0, 2.0)), d(40), d(40), PLASTER))
+    shapes.append(_grid_surface("table_top", _slab((900.0, 78.0, -600.0), (160.0, 4.0, 90.0)), d(80), d(60), WOOD))
+    for k, (sx, sz) in enumerate([(-1, -1), (1, -1), (-1, 1), (1, 1)]):
+        shapes.append(_grid_surface(f"table_leg{k}", _slab((900.0 + sx * 140.0, 37.0, -600.0 + sz * 75.0), (5.0, 37.0, 5.0)), d(16), d(24), STEEL))
+        shapes.append(_grid_surface(f"seat{k}", _ellipsoid((900.0 + sx * 230.0, 45.0, -600.0 + sz * 40.0), (42.0, 45.0, 42.0), bumps=0.05), d(90), d(60), FABRIC))
+    shapes.append(_grid_surface("mirror", _slab((1398.0, 160.0, -700.0), (1.0, 90.0, 140.0)), d(20), d(20), MIRROR))
+    shapes.append(_grid_surface("vase", _ellipsoid((900.0, 112.0, -600.0), (18.0, 30.0, 18.0), bumps=0.08, freq=(6, 4)), d(120), d(90), VASE))
+    shapes.append(_grid_surface("lamp", _ellipsoid((1150.0, 200.0, -350.0), (14.0, 14.0, 14.0)), d(30), d(20), BULB))
+    shapes.append(_grid_surface("ring", _torus((1150.0, 222.0, -350.0), 1, 30.0, 4.0), d(80), d(24), STEEL))
+    return Model(shapes, mtls)

@@ -219,6 +219,80 @@ def shuttle(width=2000, height=1200, n_samples=8192, detail=1.0, tex_size=1024):
     return assemble(cfg, blocks)
 
 
+def bike(width=1600, height=1200, n_samples=2048, detail=1.0, tex_size=1024):
+    """assets/scene/scene_bike.txt:6-52 with the motorbike replaced by the formula-1 stand-in fitted into the box a
+    model standing on that scene's ground occupies (y up before the file's `rotation 90 0 0`)."""
+    cfg = RenderConfig(width, height, n_samples, max_depth=8, fov_deg=60, gamma=1.6, russian_roulette=0.9,
+                       background=(0.05, 0.05, 0.05), camera_pos=(-1100, 0, 1000), camera_dir=(1, 0, -0.22), camera_up=(0, 0, 1))
+    model = procgen.fitted(procgen.formula1(detail=detail, tex_size=tex_size), (-260, 700, 0), (260, 1150, 1000))
+    blocks = [
+        ObjectBlock(model, "metal", position=(0, 500, -700), rotation=(90, 0, 0), albedo=(1, 1, 1), metal_fuzz=0.2, optical_density=3),
+        ObjectBlock(procgen.plane1(), "light", position=(-200, 0, 1400), rotation=(90, 0, 0), scale=(2e2, 0, 1e3), albedo=(1, 1, 1)),
+        ObjectBlock(procgen.plane1(), "light", position=(-1101, 0, 400), rotation=(0, 0, 90), scale=(1e3, 0, 1e3), albedo=(1, 1, 1)),
+        ObjectBlock(procgen.plane1(), "lambertian", rotation=(90, 0, 0), scale=(1e4, 0, 1e4), albedo=(1, 1, 1)),
+    ]
+    return assemble(cfg, blocks)
+
+
+def bunny(width=1200, height=1200, n_samples=256, bunny_tris=70_000):
+    """assets/scene/scene_bunny.txt:6-65 with bunny.obj (a single shape, no MTL) replaced by the statue generator
+    fitted into the Stanford bunny's box.  Two `simple_material` metals of different fuzz, two lights."""
+    cfg = RenderConfig(width, height, n_samples, max_depth=8, fov_deg=60, gamma=1.2, russian_roulette=0.9,
+                       background=(0.01, 0.0, 0.01), camera_pos=(0, -9, 4.5), camera_dir=(0, 1, -0.1), camera_up=(0, 0, 1))
+    model = procgen.fitted(procgen.statue(bunny_tris), (-0.095, 0.033, -0.062), (0.061, 0.187, 0.059))
+    blocks = [
+        ObjectBlock(model, "metal", position=(1, 2, -2), rotation=(90, 0, 0), scale=(50, 50, 50), albedo=(0.1, 0.1, 1.0), metal_fuzz=0.05,
+                    optical_density=3, simple_material=True),
+        ObjectBlock(procgen.box(), "metal", position=(1.2, -1.5, 0.5), rotation=(0, 0, 15), albedo=(1, 0.1, 0.1), metal_fuzz=0.5,
+                    optical_density=3, simple_material=True),
+        ObjectBlock(procgen.plane1(), "light", position=(0, -10, 0), scale=(5, 0, 5), albedo=(1, 1, 1)),
+        ObjectBlock(procgen.plane1(), "light", position=(0, 0, 10), rotation=(90, 0, 0), scale=(5, 0, 5), albedo=(1, 1, 1)),
+        ObjectBlock(procgen.plane1(), "lambertian", rotation=(90, 0, 0), scale=(10, 0, 10), albedo=(1, 1, 1)),
+    ]
+    return assemble(cfg, blocks)
+
+
+def cat(width=600, height=600, n_samples=32, detail=1.0, tex_size=512):
+    """assets/scene/scene_cat.txt:6-38 with the cat replaced by the shuttle stand-in fitted into a box the camera sees.
+    The only light is a plane scaled by 1e4 on every axis, tilted 60 degrees about z."""
+    cfg = RenderConfig(width, height, n_samples, max_depth=8, fov_deg=45, gamma=1.0, russian_roulette=0.9,
+                       background=(0.1, 0.1, 0.1), camera_pos=(3, 0, 3), camera_dir=(-1, 0, 0), camera_up=(0, 0, 1))
+    model = procgen.fitted(procgen.shuttle(detail=detail, tex_size=tex_size), (-14, -14, 32), (14, 14, 66))
+    blocks = [
+        ObjectBlock(model, "lambertian", position=(-3, 0.0, -2), rotation=(0, 0, 45), scale=(0.1, 0.1, 0.1), albedo=(1, 1, 1), metal_fuzz=0.01,
+                    optical_density=3),
+        ObjectBlock(procgen.plane1(), "light", position=(5, 4, 0), rotation=(0, 0, -60), scale=(1e4, 1e4, 1e4), albedo=(1, 1, 1)),
+    ]
+    return assemble(cfg, blocks)
+
+
+def house(width=600, height=600, n_samples=32, detail=1.0, tex_size=512):
+    """assets/scene/scene_house.txt:6-46 with the bamboo house replaced by the shuttle stand-in (y up, as the file's
+    `rotation 90 36 0` expects) between a light plane 100 above and a white plane 100 below."""
+    cfg = RenderConfig(width, height, n_samples, max_depth=8, fov_deg=45, gamma=1.0, russian_roulette=0.9,
+                       background=(0.05, 0.05, 0.05), camera_pos=(10, 0, 0), camera_dir=(-1, 0, 0.1), camera_up=(0, 0, 1))
+    model = procgen.fitted(procgen.shuttle(detail=detail, tex_size=tex_size), (-6, 0, -6), (6, 7, 6))
+    blocks = [
+        ObjectBlock(model, "lambertian", position=(0, -2, -0.2), rotation=(90, 36, 0), scale=(0.4, 0.4, 0.4), albedo=(1, 1, 1), metal_fuzz=0.2,
+                    optical_density=3),
+        ObjectBlock(procgen.plane1(), "light", position=(0, 0, 100), rotation=(90, 0, 0), scale=(1e6, 1e6, 1e6), albedo=(1, 1, 1)),
+        ObjectBlock(procgen.plane1(), "lambertian", position=(0, 0, -100), rotation=(90, 0, 0), scale=(1e6, 1e6, 1e6), albedo=(1, 1, 1)),
+    ]
+    return assemble(cfg, blocks)
+
+
+def room(width=1200, height=800, n_samples=512, detail=1.0, tex_size=256):
+    """assets/scene/scene_room.txt:6-38: a y-up interior at ray depth 16, the camera inside the model, one ceiling
+    light; the room model replaced by procgen.room."""
+    cfg = RenderConfig(width, height, n_samples, max_depth=16, fov_deg=60, gamma=1.0, russian_roulette=0.9,
+                       background=(0.05, 0.05, 0.05), camera_pos=(600, 100, -900), camera_dir=(1, 0, 1), camera_up=(0, 1, 0))
+    blocks = [
+        ObjectBlock(procgen.room(detail=detail, tex_size=tex_size), "lambertian", albedo=(1, 1, 1), metal_fuzz=0.2, optical_density=3),
+        ObjectBlock(procgen.plane1(), "light", position=(693, 290, -820), scale=(164, 0, 160), albedo=(1, 1, 1)),
+    ]
+    return assemble(cfg, blocks)
+
+
 def stress(width=3840, height=2160, n_samples=1024, grid=(8, 8), tris_per_instance=470_000):
     """Many rotated/translated instances of a bumpy blob on a ground plane under one large light."""
     cfg = RenderConfig(width, height, n_samples, max_depth=8, fov_deg=55, gamma=1.8, russian_roulette=0.9,

@@ -142,6 +142,10 @@ def test_closest_hit_golden_fixture(gpu_ctx):
     ("luyu", dict(width=200, height=120, n_samples=4, statue_tris=60000)),
     ("formula1", dict(width=200, height=120, n_samples=4, detail=0.15, tex_size=128)),
     ("shuttle", dict(width=200, height=120, n_samples=4, detail=0.15, tex_size=128)),
+    ("bike", dict(width=160, height=120, n_samples=4, detail=0.15, tex_size=64)),
+    ("bunny", dict(width=120, height=120, n_samples=4, bunny_tris=40000)),
+    ("house", dict(width=120, height=120, n_samples=4, detail=0.15, tex_size=64)),
+    ("room", dict(width=150, height=100, n_samples=4, detail=0.5, tex_size=64)),
 ])
 def test_closest_hit_bit_exact_benchmark_scenes(gpu_ctx, name, kw):
     p = Pair(gpu_ctx, getattr(scene, name)(**kw))
@@ -161,6 +165,10 @@ def test_closest_hit_bit_exact_benchmark_scenes(gpu_ctx, name, kw):
     ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 8, 8),
     ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 4),
     ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 2),
+    ("bike", dict(width=80, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 4),
+    ("bunny", dict(width=64, height=64, n_samples=8, bunny_tris=8000), 8, 8),                 # rough and smooth metal
+    ("cat", dict(width=64, height=64, n_samples=6, detail=0.05, tex_size=64), 6, 4),            # partial last batch
+    ("room", dict(width=60, height=40, n_samples=8, detail=0.2, tex_size=64), 8, 4),            # ray depth 16, camera inside
 ])
 def test_radiance_sums_and_counters_bit_exact(gpu_ctx, name, kw, spp, batch):
     p = Pair(gpu_ctx, getattr(scene, name)(**kw))
@@ -181,6 +189,8 @@ def test_radiance_sums_and_counters_bit_exact(gpu_ctx, name, kw, spp, batch):
     ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 8, 8, 14),
     ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 4, 22),   # pool larger than the job
     ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 8, 2, 12),
+    ("room", dict(width=60, height=40, n_samples=8, detail=0.2, tex_size=64), 8, 4, 13),        # 16 bounces through a small pool
+    ("house", dict(width=64, height=64, n_samples=8, detail=0.05, tex_size=64), 8, 8, 14),
 ])
 def test_wavefront_variant_bit_exact(gpu_ctx, name, kw, spp, batch, cap):
     """The wavefront schedule (state in HBM, stage kernels, ballot compaction) traces the same paths: same image, same counts."""

@@ -264,6 +264,11 @@ def summary(stdout):
     ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, glass=True)),              # simple_material
     ("shuttle", dict(width=64, height=40, n_samples=4, detail=0.05, tex_size=32)),
     ("luyu", dict(width=64, height=40, n_samples=4, statue_tris=3000)),
+    ("bike", dict(width=64, height=48, n_samples=4, detail=0.03, tex_size=16)),                 # fitted model far from the origin
+    ("bunny", dict(width=48, height=48, n_samples=4, bunny_tris=2000)),                         # scale 50 on a 0.15-unit mesh
+    ("cat", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),
+    ("house", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),                # planes scaled by 1e6
+    ("room", dict(width=48, height=32, n_samples=4, detail=0.1, tex_size=16)),                  # y-up camera, depth 16
 ])
 def test_scene_loader_matches_python_assembly(tmp_path, name, kw):
     asm = getattr(scene, name)(**kw)
