@@ -341,6 +341,44 @@ def test_full_size_primary_hits_agree_with_oracle_sample(gpu_ctx):
     assert 0.3 < (go >= 0).mean() <= 1.0
 
 
+def test_incoherent_secondary_rays_at_full_detail(gpu_ctx):
+    """Rays the way bounces produce them: origins on the surfaces the camera sees, directions uniform on the sphere, on
+    the full benchmark geometry.  Every one of 400k rays is compared with the oracle, not a sample."""
+    p = Pair(gpu_ctx, scene.formula1(width=2000, height=1200, n_samples=1))
+    rays = p.gpu_primary_rays(0)
+    go, gt, gtt, gu, gv = p.gpu_hits(rays)
+    rng = np.random.RandomState(17)
+    pick = rng.choice(np.nonzero(go >= 0)[0], size=400_000, replace=False)
+    origin = rays[pick, :3] + rays[pick, 3:] * gtt[pick, None]
+    d = rng.standard_normal((len(pick), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = np.concatenate([origin, d], axis=1).astype(np.float32)
+    hit = p.check_hits(sec)
+    assert 0.5 < (hit >= 0).mean() < 1.0                       # most leave a surface into the scene, some escape
+
+
+@pytest.mark.parametrize("name,kw,spp,batch", [
+    ("formula1", dict(width=400, height=240, n_samples=16), 16, 16),                            # full detail: 513k triangles, 1024^2 textures
+    ("formula1", dict(width=2000, height=1200, n_samples=2), 2, 2),                             # the benchmark's frame, every pixel
+    ("formula1", dict(width=500, height=300, n_samples=8, glass=True), 8, 8),                   # all-refractive variant at full detail
+    ("shuttle", dict(width=500, height=300, n_samples=8), 8, 4),
+    ("stress", dict(width=320, height=180, n_samples=8, grid=(3, 3), tris_per_instance=50_000), 8, 4),
+])
+def test_full_detail_wavefront_render_bit_exact(gpu_ctx, name, kw, spp, batch):
+    """The benchmark's kernel design and default options on benchmark-sized geometry, whole buffer against the oracle."""
+    p = Pair(gpu_ctx, getattr(scene, name)(**kw))
+    ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, batch), 0, spp)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 19)
+    try:
+        got, gcnt = p.gpu_render(0, spp, batch)
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2] and gcnt[capi.CNT_SHADED] == rcnt[3]
+
+
 def test_rmse_to_a_converged_image(gpu_ctx):
     """Statistical agreement, seed-independent: GPU frames with one seed against an oracle frame with another seed and
     many more samples.  The error must fall like 1/sqrt(spp) (tolerance: a 16x sample count must cut the RMSE by at
