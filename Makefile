@@ -3,7 +3,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 CSRC     := raytrace_amd/csrc
 # -ffp-contract=off is part of the numeric contract (bit-reproducible hit records).
-HIPFLAGS := -std=c++17 -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS := -std=c++17 -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wextra -Wno-unused-parameter $(EXTRA_HIPFLAGS)
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra
 
 LIB := raytrace_amd/librtcore.so

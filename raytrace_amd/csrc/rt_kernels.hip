@@ -263,6 +263,16 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
 
+// Waves per SIMD the register allocator must leave room for in wf_extend_kernel (0 = its own choice).
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 0
+#endif
+#if RT_EXTEND_WAVES > 0
+#define RT_EXTEND_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RT_EXTEND_WAVES, RT_EXTEND_WAVES)))
+#else
+#define RT_EXTEND_OCCUPANCY
+#endif
+
 // Closest hit for every pooled path.  Traversal lengths differ wildly between the rays of a wave, so a lane does
 // not own one ray and a wave does not own a fixed share of the pool: the launch fills the chip once, every wave
 // claims `chunk` consecutive pool entries at a time (one returning atomic per chunk, on the queue word of its XCD's
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 // k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
 // lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
+__global__ __launch_bounds__(RT_BLOCK) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
                                                              int vote_leaf_weight, int refill_min,
                                                              unsigned long long* counters) {
