@@ -39,6 +39,7 @@ OPT_WF_SORT = 10
 OPT_HOT_NODES = 12
 OPT_WF_VOTE = 13
 OPT_WF_REFILL = 14
+OPT_WF_BLOCK = 15
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 
 

@@ -263,6 +263,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
 
+// Largest workgroup of wf_extend_kernel (its size is a launch parameter: the workgroups of a CU each keep their own
+// LDS copy of the hot nodes, so fewer, larger workgroups leave room for more hot nodes).
+#define RT_EXTEND_BLOCK_MAX 1024
 // Waves per SIMD the register allocator must leave room for in wf_extend_kernel (0 = its own choice).
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 0
@@ -282,17 +285,18 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 // k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
 // lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
+__global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
                                                              int vote_leaf_weight, int refill_min,
                                                              unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     // behind the stacks, inside the one dynamic LDS block: copies of the first n_hot node records
-    lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * RT_BLOCK);
+    const uint32_t block = blockDim.x;
+    lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * block);
     const uint32_t count = ctl->count[nxt];
     TravCounters tc = {};
-    for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += RT_BLOCK) {
+    for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += block) {
         const float4 v = reinterpret_cast<const float4*>(sc.nodes)[k];
         f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
         hot[(k >> 3) * (RT_HOT_STRIDE / 16) + (k & 7u)] = o;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(RT_BLOCK) RT_EXTEND_OCCUPANCY void wf_extend_kernel
     const int lane = threadIdx.x & 63;
     uint2 spill[RT_SPILL_SLOTS];
     Walker<COUNT> w;
-    w.init(stack, RT_BLOCK, lds_slots, spill);
+    w.init(stack, (int)block, lds_slots, spill);
     w.set_hot(hot, n_hot);
     RayD r;
     ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
@@ -600,7 +604,7 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
-    int opt_lds_slots = 8;           // stack levels kept in LDS (deeper ones spill to private memory)
+    int opt_lds_slots = 9;           // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 1024;             // samples per pixel held in the slot buffer at once (less when that would exceed RT_SLOTS_MAX_BYTES)
     int opt_timing = 0;              // record HIP events around the traversal kernels
@@ -615,7 +619,9 @@ struct rt_context {
     int opt_wf_sort = 1;             // shade kernel files surviving rays by direction octant
     int opt_wf_vote = 32;            // 0 = fixed node burst; k > 0 = per-trip vote, a leaf visit weighs k/16 node visits
     int opt_wf_refill = 16;          // vote policy: idle lanes that trigger a refill
-    int opt_hot_nodes = 32;          // node records (breadth-first prefix) the extend kernel keeps in LDS
+    size_t extend_lds_limit = 64 * 1024;   // dynamic LDS the extend kernel may currently be launched with
+    int opt_wf_block = 512;          // lanes per workgroup of the extend kernel: three workgroups of eight waves per CU
+    int opt_hot_nodes = 100;         // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     WfPools pools{};
     int n_cu = 256;                  // compute units of the device
@@ -729,6 +735,9 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_WF_REFILL:
         if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "rt_set_option: refill threshold must be 1..64 lanes");
         ctx->opt_wf_refill = value; return RT_OK;
+    case RT_OPT_WF_BLOCK:
+        if (value < 64 || value > RT_EXTEND_BLOCK_MAX || value % 64) return fail(RT_ERR_INVALID, "rt_set_option: closest-hit workgroup must be a multiple of 64 up to 1024 lanes");
+        ctx->opt_wf_block = value; return RT_OK;
     case RT_OPT_HOT_NODES:
         if (value < 0 || value > 512) return fail(RT_ERR_INVALID, "rt_set_option: hot nodes must be 0..512");
         ctx->opt_hot_nodes = value; return RT_OK;
@@ -918,16 +927,23 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
         // one launch fills the chip once (8 workgroups of 4 waves per CU at most); the waves share out the pool themselves
         const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
-        const uint32_t wanted = (cap + rpb * (RT_BLOCK / 64) - 1) / (rpb * (RT_BLOCK / 64));
-        const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * 8u));
+        const uint32_t eb = (uint32_t)ctx->opt_wf_block;
+        const uint32_t wanted = (cap + rpb * (eb / 64) - 1) / (rpb * (eb / 64));
+        const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * (2048u / eb))), eblock(eb);
         const int tke = timing_begin(ctx, 0, s);
         const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
-        const size_t elds = stack_bytes(ctx) + (size_t)n_hot * RT_HOT_STRIDE;
+        const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE;
+        if (elds > ctx->extend_lds_limit) {               // more than the default 64 KB of dynamic LDS has to be asked for once
+            if (elds > 160u * 1024u) return fail(RT_ERR_INVALID, "rt_raytrace: stack slots and hot nodes need more than 160 KB of LDS per workgroup");
+            HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+            HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+            ctx->extend_lds_limit = elds;
+        }
         if (ctx->opt_counters)
-            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, block, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
+            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, eblock, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
                                slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
         else
-            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, block, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
+            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, eblock, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
                                slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
         timing_end(ctx, tke, s);
         HIP_TRY(hipGetLastError());

@@ -229,28 +229,30 @@ def test_wavefront_depth_zero_and_glass(gpu_ctx):
 
 
 def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
-    """Octant-ordered compaction, the LDS node cache, node burst and run length only reschedule work."""
+    """Octant-ordered compaction, the LDS node cache, node burst, run length and workgroup size only reschedule work."""
     p = Pair(gpu_ctx, scene.formula1(width=96, height=60, n_samples=8, detail=0.05, tex_size=64))
     ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, 4), 0, 8)
     gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
     gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 13)
     try:
-        for sort, hot, burst, run, vote, refill in ((0, 0, 1, 64, 0, 8), (1, 0, 4, 1024, 16, 8), (0, 64, 2, 100, 4, 1), (1, 512, 7, 4096, 64, 64),
-                                                   (1, 3, 4, 1024, 1024, 20)):
+        for sort, hot, burst, run, vote, refill, block in ((0, 0, 1, 64, 0, 8, 64), (1, 0, 4, 1024, 16, 8, 256), (0, 64, 2, 100, 4, 1, 768),
+                                                          (1, 512, 7, 4096, 64, 64, 1024), (1, 3, 4, 1024, 1024, 20, 512), (1, 140, 4, 256, 32, 16, 192)):
             gpu_ctx.set_option(capi.OPT_WF_VOTE, vote)
             gpu_ctx.set_option(capi.OPT_WF_REFILL, refill)
             gpu_ctx.set_option(capi.OPT_WF_SORT, sort)
             gpu_ctx.set_option(capi.OPT_HOT_NODES, hot)
             gpu_ctx.set_option(capi.OPT_WF_BURST, burst)
             gpu_ctx.set_option(capi.OPT_WF_RUN, run)
+            gpu_ctx.set_option(capi.OPT_WF_BLOCK, block)
             got, gcnt = p.gpu_render(0, 8, 4)
-            assert same_f32(got, ref), (sort, hot, burst, run, vote, refill)
-            assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2], (sort, hot, burst, run, vote, refill)
+            assert same_f32(got, ref), (sort, hot, burst, run, vote, refill, block)
+            assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2], (sort, hot, burst, run, vote, refill, block)
     finally:
         gpu_ctx.set_option(capi.OPT_WF_SORT, 1)
         gpu_ctx.set_option(capi.OPT_WF_VOTE, 32)
         gpu_ctx.set_option(capi.OPT_WF_REFILL, 16)
-        gpu_ctx.set_option(capi.OPT_HOT_NODES, 32)
+        gpu_ctx.set_option(capi.OPT_HOT_NODES, 100)
+        gpu_ctx.set_option(capi.OPT_WF_BLOCK, 512)
         gpu_ctx.set_option(capi.OPT_WF_BURST, 4)
         gpu_ctx.set_option(capi.OPT_WF_RUN, 256)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
