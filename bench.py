@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--wf-vote", type=int, default=-1)
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
+    ap.add_argument("--wf-lanes", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
     args = ap.parse_args()
 
@@ -147,6 +148,8 @@ def main():
         ctx.set_option(capi.OPT_HOT_NODES, args.hot_nodes)
     if args.wf_block:
         ctx.set_option(capi.OPT_WF_BLOCK, args.wf_block)
+    if args.wf_lanes:
+        ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height

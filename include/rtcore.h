@@ -133,7 +133,8 @@ enum {
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
                                  In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
-    RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = 2^value paths (default 25; 7 * 16 bytes of HBM per path) */
+    RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = at most 2^value paths (default 27; 7 * 16 bytes of HBM per path, 15 GB at the default), never more
+                                 than a pass has paths; a long closest-hit launch hides the wait for its last long rays better than a short one */
     RT_OPT_WF_RUN = 8,        /* wavefront: pool entries a closest-hit wave claims from the queue at a time (default 256, >= 64); scheduling only */
     RT_OPT_WF_SORT = 10,      /* wavefront: 1 = each shading workgroup files its surviving rays by direction octant (default), 0 = plain order;
                                  scheduling only */
@@ -143,6 +144,9 @@ enum {
                                  the wave runs the visit kind most lanes wait for, a leaf visit weighing k/16 node visits; scheduling only */
     RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 16) */
     RT_OPT_WF_BLOCK = 15,     /* wavefront closest-hit: lanes per workgroup (default 512; a multiple of 64 up to 1024); scheduling only */
+    RT_OPT_WF_LANES = 16,     /* wavefront: independent pipelines a pass's samples are split over, each on a stream of its own, so that
+                                 one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);
+                                 scheduling only */
     RT_OPT_WF_BURST = 9       /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
 };
 

@@ -40,6 +40,7 @@ OPT_HOT_NODES = 12
 OPT_WF_VOTE = 13
 OPT_WF_REFILL = 14
 OPT_WF_BLOCK = 15
+OPT_WF_LANES = 16
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 
 

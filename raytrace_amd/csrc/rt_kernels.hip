@@ -614,7 +614,7 @@ struct rt_context {
     double time_ms[3] = {0, 0, 0};
     uint64_t time_launches[3] = {0, 0, 0};
     int opt_mode = 1;                // 0 = megakernel (path_kernel), 1 = wavefront (stage kernels)
-    int opt_wf_log2 = 25;            // wavefront pool capacity = 2^this paths
+    int opt_wf_log2 = 27;            // wavefront pool capacity = 2^this paths
     int opt_wf_run = 256;            // pool entries a closest-hit wave claims from the queue at a time
     int opt_wf_sort = 1;             // shade kernel files surviving rays by direction octant
     int opt_wf_vote = 32;            // 0 = fixed node burst; k > 0 = per-trip vote, a leaf visit weighs k/16 node visits
@@ -623,11 +623,22 @@ struct rt_context {
     int opt_wf_block = 512;          // lanes per workgroup of the extend kernel: three workgroups of eight waves per CU
     int opt_hot_nodes = 100;         // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
-    WfPools pools{};
     int n_cu = 256;                  // compute units of the device
-    WfCtl* d_ctl = nullptr;
-    WfCtl* h_ctl = nullptr;          // pinned ring of control-block snapshots
-    hipEvent_t ctl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // The wavefront variant runs up to RT_WF_LANES_MAX independent pipelines ("lanes" of the host loop, nothing to do
+    // with SIMD lanes), each with its own pools, control block and stream: while one pipeline's closest-hit launch
+    // waits for its last long rays, the other pipeline's kernels fill the CUs that have already gone idle.
+    struct WfLane {
+        WfPools pools = {};
+        WfCtl* d_ctl = nullptr;
+        WfCtl* h_ctl = nullptr;      // pinned ring of control-block snapshots
+        hipEvent_t ctl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    WfLane lanes[2];
+    hipEvent_t fork_ev = nullptr;
+    int lanes_allocated = 0;
+    int opt_wf_lanes = 1;            // pipelines per pass (2 measured slower: the second pipeline's shading starves behind the first's closest-hit launch)
     uint32_t pool_capacity = 0;
     float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
@@ -642,18 +653,27 @@ static void free_scene(rt_context* c) {
 }
 
 static void free_pools(rt_context* c) {
-    for (int k = 0; k < 2; k++) {
-        if (c->pools.p0[k]) (void)hipFree(c->pools.p0[k]);
-        if (c->pools.p1[k]) (void)hipFree(c->pools.p1[k]);
-        if (c->pools.p2[k]) (void)hipFree(c->pools.p2[k]);
-        c->pools.p0[k] = c->pools.p1[k] = c->pools.p2[k] = nullptr;
+    for (rt_context::WfLane& l : c->lanes) {
+        for (int k = 0; k < 2; k++) {
+            if (l.pools.p0[k]) (void)hipFree(l.pools.p0[k]);
+            if (l.pools.p1[k]) (void)hipFree(l.pools.p1[k]);
+            if (l.pools.p2[k]) (void)hipFree(l.pools.p2[k]);
+            l.pools.p0[k] = l.pools.p1[k] = l.pools.p2[k] = nullptr;
+        }
+        if (l.pools.hit) (void)hipFree(l.pools.hit);
+        l.pools.hit = nullptr;
+        if (l.d_ctl) (void)hipFree(l.d_ctl);
+        if (l.h_ctl) (void)hipHostFree(l.h_ctl);
+        for (auto& e : l.ctl_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        l.d_ctl = nullptr; l.h_ctl = nullptr;
+        if (l.done) (void)hipEventDestroy(l.done);
+        l.done = nullptr;
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        l.stream = nullptr;
     }
-    if (c->pools.hit) (void)hipFree(c->pools.hit);
-    c->pools.hit = nullptr;
-    if (c->d_ctl) (void)hipFree(c->d_ctl);
-    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    for (auto& e : c->ctl_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    c->d_ctl = nullptr; c->h_ctl = nullptr;
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    c->fork_ev = nullptr;
+    c->lanes_allocated = 0;
     c->pool_capacity = 0;
 }
 
@@ -735,6 +755,9 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_WF_REFILL:
         if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "rt_set_option: refill threshold must be 1..64 lanes");
         ctx->opt_wf_refill = value; return RT_OK;
+    case RT_OPT_WF_LANES:
+        if (value < 1 || value > 2) return fail(RT_ERR_INVALID, "rt_set_option: pipelines per pass must be 1 or 2");
+        ctx->opt_wf_lanes = value; return RT_OK;
     case RT_OPT_WF_BLOCK:
         if (value < 64 || value > RT_EXTEND_BLOCK_MAX || value % 64) return fail(RT_ERR_INVALID, "rt_set_option: closest-hit workgroup must be a multiple of 64 up to 1024 lanes");
         ctx->opt_wf_block = value; return RT_OK;
@@ -891,78 +914,123 @@ static void timing_collect(rt_context* ctx) {
 #define RT_SLOTS_MAX_BYTES ((size_t)64 << 30)
 #define RT_CTL_RING 4
 #define RT_CTL_GROUP 4
-// One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.
+// One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
+// samples are split between the pipelines; every path writes its own slot, so the split changes no result.
 static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
-    const uint32_t cap = 1u << ctx->opt_wf_log2;
-    if (ctx->pool_capacity != cap) {
+    const int n_lanes = (ctx->opt_wf_lanes > 1 && pp.n_samples > 1) ? 2 : 1;
+    // pool size: the option's, but no larger than the pass needs (a small frame should not launch grids sized for a
+    // large one, nor hold gigabytes of pools); the pools only ever grow
+    const unsigned long long pass_paths = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
+    uint32_t cap = 1u << ctx->opt_wf_log2;
+    while (cap > (1u << 16) && (unsigned long long)(cap >> 1) >= pass_paths) cap >>= 1;
+    if (ctx->pool_capacity < cap || ctx->lanes_allocated < n_lanes) {
         HIP_TRY(hipStreamSynchronize(s));
         free_pools(ctx);
-        for (int k = 0; k < 2; k++) {
-            HIP_TRY(hipMalloc((void**)&ctx->pools.p0[k], (size_t)cap * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&ctx->pools.p1[k], (size_t)cap * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&ctx->pools.p2[k], (size_t)cap * sizeof(float4)));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        for (int l = 0; l < n_lanes; l++) {
+            rt_context::WfLane& L = ctx->lanes[l];
+            for (int k = 0; k < 2; k++) {
+                HIP_TRY(hipMalloc((void**)&L.pools.p0[k], (size_t)cap * sizeof(float4)));
+                HIP_TRY(hipMalloc((void**)&L.pools.p1[k], (size_t)cap * sizeof(float4)));
+                HIP_TRY(hipMalloc((void**)&L.pools.p2[k], (size_t)cap * sizeof(float4)));
+            }
+            HIP_TRY(hipMalloc((void**)&L.pools.hit, (size_t)cap * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&L.d_ctl, sizeof(WfCtl)));
+            HIP_TRY(hipHostMalloc((void**)&L.h_ctl, RT_CTL_RING * sizeof(WfCtl), hipHostMallocDefault));
+            for (int k = 0; k < RT_CTL_RING; k++) HIP_TRY(hipEventCreateWithFlags(&L.ctl_ev[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         }
-        HIP_TRY(hipMalloc((void**)&ctx->pools.hit, (size_t)cap * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&ctx->d_ctl, sizeof(WfCtl)));
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_ctl, RT_CTL_RING * sizeof(WfCtl), hipHostMallocDefault));
-        for (int k = 0; k < RT_CTL_RING; k++) HIP_TRY(hipEventCreateWithFlags(&ctx->ctl_ev[k], hipEventDisableTiming));
+        ctx->lanes_allocated = n_lanes;
         ctx->pool_capacity = cap;
     }
-    const unsigned long long total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
-    HIP_TRY(hipMemsetAsync(ctx->d_ctl, 0, sizeof(WfCtl), s));
-    const dim3 grid(cap / RT_BLOCK), block(RT_BLOCK);
     const int slots_lds = lds_slots(ctx);
-    int cur = 0;
-    int snap_cur[RT_CTL_RING] = {0, 0, 0, 0};
-    for (unsigned iter = 0;; iter++) {
-        const int nxt = cur ^ 1;
-        if (iter > 0) {
-            const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
-            const int tk = timing_begin(ctx, 1, s);
-            if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
-            else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, s, ctx->dev, ctx->d_ctl, ctx->pools, cur, pp);
-            timing_end(ctx, tk, s);
-        }
-        hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, s, ctx->d_ctl, nxt, total, cap, ctx->d_counters);
-        hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, s, (const WfCtl*)ctx->d_ctl, ctx->pools, nxt, pp);
-        // one launch fills the chip once (8 workgroups of 4 waves per CU at most); the waves share out the pool themselves
-        const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
-        const uint32_t eb = (uint32_t)ctx->opt_wf_block;
-        const uint32_t wanted = (cap + rpb * (eb / 64) - 1) / (rpb * (eb / 64));
-        const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * (2048u / eb))), eblock(eb);
-        const int tke = timing_begin(ctx, 0, s);
-        const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
-        const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE;
-        if (elds > ctx->extend_lds_limit) {               // more than the default 64 KB of dynamic LDS has to be asked for once
-            if (elds > 160u * 1024u) return fail(RT_ERR_INVALID, "rt_raytrace: stack slots and hot nodes need more than 160 KB of LDS per workgroup");
-            HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
-            HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
-            ctx->extend_lds_limit = elds;
-        }
-        if (ctx->opt_counters)
-            hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, eblock, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
-        else
-            hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, eblock, elds, s, ctx->dev, ctx->d_ctl, ctx->pools, nxt,
-                               slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
-        timing_end(ctx, tke, s);
-        HIP_TRY(hipGetLastError());
-        cur = nxt;
-        // The host does not know the pool's population.  After every group of iterations it queues a snapshot
-        // of the control block, and it reads the snapshot of the group BEFORE, so the stream always holds
-        // a group of work while the host waits; the price is one group of empty launches at the very end.
-        if ((iter % RT_CTL_GROUP) == RT_CTL_GROUP - 1) {
-            const unsigned g = iter / RT_CTL_GROUP;
-            HIP_TRY(hipMemcpyAsync(&ctx->h_ctl[g % RT_CTL_RING], ctx->d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipEventRecord(ctx->ctl_ev[g % RT_CTL_RING], s));
-            snap_cur[g % RT_CTL_RING] = cur;
-            if (g > 0) {
-                const unsigned q = (g - 1) % RT_CTL_RING;
-                HIP_TRY(hipEventSynchronize(ctx->ctl_ev[q]));
-                if (ctx->h_ctl[q].cursor >= total && ctx->h_ctl[q].count[snap_cur[q]] == 0) break;
+    const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
+    const uint32_t eb = (uint32_t)ctx->opt_wf_block;
+    const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
+    const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE;
+    if (elds > ctx->extend_lds_limit) {               // more than the default 64 KB of dynamic LDS has to be asked for once
+        if (elds > 160u * 1024u) return fail(RT_ERR_INVALID, "rt_raytrace: stack slots and hot nodes need more than 160 KB of LDS per workgroup");
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        ctx->extend_lds_limit = elds;
+    }
+    // the pipelines start after the work already queued on the caller's stream and hand back to it at the end
+    HIP_TRY(hipEventRecord(ctx->fork_ev, s));
+    struct LaneRun {
+        PathParams pp;
+        unsigned long long total;
+        int cur;
+        int snap_cur[RT_CTL_RING];
+        unsigned iter;
+        bool drained;
+    } run[2];
+    for (int l = 0; l < n_lanes; l++) {
+        rt_context::WfLane& L = ctx->lanes[l];
+        LaneRun& R = run[l];
+        const int first = (int)((long long)pp.n_samples * l / n_lanes), last = (int)((long long)pp.n_samples * (l + 1) / n_lanes);
+        R.pp = pp;
+        R.pp.first_sample = pp.first_sample + first;
+        R.pp.n_samples = last - first;
+        R.pp.slots = pp.slots + (size_t)first * (size_t)pp.n_pixel * 3;
+        R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_samples;
+        R.cur = 0;
+        for (int& c : R.snap_cur) c = 0;
+        R.iter = 0;
+        R.drained = false;
+        HIP_TRY(hipStreamWaitEvent(L.stream, ctx->fork_ev, 0));
+        HIP_TRY(hipMemsetAsync(L.d_ctl, 0, sizeof(WfCtl), L.stream));
+    }
+    const dim3 grid(cap / RT_BLOCK), block(RT_BLOCK);
+    const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
+    // one launch fills the chip once; the waves share out the pool themselves
+    const uint32_t wanted = (cap + rpb * (eb / 64) - 1) / (rpb * (eb / 64));
+    const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * (2048u / eb))), eblock(eb);
+    for (int live = n_lanes; live > 0;) {
+        for (int l = 0; l < n_lanes; l++) {
+            rt_context::WfLane& L = ctx->lanes[l];
+            LaneRun& R = run[l];
+            if (R.drained) continue;
+            hipStream_t ls = L.stream;
+            const int nxt = R.cur ^ 1;
+            if (R.iter > 0) {
+                const int tk = timing_begin(ctx, 1, ls);
+                if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, R.pp);
+                else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, R.pp);
+                timing_end(ctx, tk, ls);
             }
+            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, ls, L.d_ctl, nxt, R.total, cap, ctx->d_counters);
+            hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, R.pp);
+            const int tke = timing_begin(ctx, 0, ls);
+            if (ctx->opt_counters)
+                hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
+                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
+            else
+                hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
+                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
+            timing_end(ctx, tke, ls);
+            HIP_TRY(hipGetLastError());
+            R.cur = nxt;
+            // The host does not know the pool's population.  After every group of iterations it queues a snapshot
+            // of the control block, and it reads the snapshot of the group BEFORE, so the stream always holds
+            // a group of work while the host waits; the price is one group of empty launches at the very end.
+            if ((R.iter % RT_CTL_GROUP) == RT_CTL_GROUP - 1) {
+                const unsigned g = R.iter / RT_CTL_GROUP;
+                HIP_TRY(hipMemcpyAsync(&L.h_ctl[g % RT_CTL_RING], L.d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, ls));
+                HIP_TRY(hipEventRecord(L.ctl_ev[g % RT_CTL_RING], ls));
+                R.snap_cur[g % RT_CTL_RING] = R.cur;
+                if (g > 0) {
+                    const unsigned q = (g - 1) % RT_CTL_RING;
+                    HIP_TRY(hipEventSynchronize(L.ctl_ev[q]));
+                    if (L.h_ctl[q].cursor >= R.total && L.h_ctl[q].count[R.snap_cur[q]] == 0) { R.drained = true; live--; }
+                }
+            }
+            if (++R.iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
         }
-        if (iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
+    }
+    for (int l = 0; l < n_lanes; l++) {
+        HIP_TRY(hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->lanes[l].done, 0));
     }
     return RT_OK;
 }
