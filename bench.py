@@ -187,7 +187,7 @@ def main():
     ctx.set_option(capi.OPT_TIMING, 1)
     ctx.reset_counters()
     scratch = torch.zeros_like(accum)
-    inst_spp = min(spp, int(os.environ.get("RT_BENCH_INST_SPP", "32")))
+    inst_spp = min(spp, int(os.environ.get("RT_BENCH_INST_SPP", "256")))
     ctx.raytrace(npix, first_sample(0), inst_spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
                  scratch.data_ptr(), stream)
     c = ctx.counters()
