@@ -265,6 +265,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 
 // Largest workgroup of wf_extend_kernel (its size is a launch parameter: the workgroups of a CU each keep their own
 // LDS copy of the hot nodes, so fewer, larger workgroups leave room for more hot nodes).
+#define RT_CNT_SPREAD 64u            // places the per-workgroup additions to RT_CNT_PATHS / RT_CNT_RAYS are spread over
+#define RT_CNT_SPREAD_STRIDE 16u     // 64-bit words between two places: one 128-byte line each
+#define RT_CNT_WORDS (RT_CNT_COUNT + RT_CNT_SPREAD * RT_CNT_SPREAD_STRIDE)
 #define RT_EXTEND_BLOCK_MAX 1024
 // Waves per SIMD the register allocator must leave room for in wf_extend_kernel (0 = its own choice).
 #ifndef RT_EXTEND_WAVES
@@ -508,8 +511,11 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
         if (lane == 0) {
             block_base = total ? atomicAdd(&ctl->count[nxt], total) : 0u;
             const uint32_t fin = fr & 0xFFFFu, rays = fr >> 16;
-            if (fin) atomicAdd(pp.counters + RT_CNT_PATHS, (unsigned long long)fin);
-            if (rays) atomicAdd(pp.counters + RT_CNT_RAYS, (unsigned long long)rays);   // one closest-hit query was traced per live path
+            // finished paths and traced rays (one closest-hit query per live path): every workgroup adds its sums, so
+            // the additions are spread over RT_CNT_SPREAD cache lines -- on one word they would queue up behind each other
+            unsigned long long* spread = pp.counters + RT_CNT_COUNT + (blockIdx.x & (RT_CNT_SPREAD - 1u)) * RT_CNT_SPREAD_STRIDE;
+            if (fin) atomicAdd(spread, (unsigned long long)fin);
+            if (rays) atomicAdd(spread + 1, (unsigned long long)rays);
         }
     }
     __syncthreads();
@@ -716,9 +722,9 @@ int rt_create(int device_id, rt_context** out) {
     c->device = device_id;
     (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
     if (c->n_cu <= 0) c->n_cu = 256;
-    hipError_t e = hipMalloc((void**)&c->d_counters, RT_CNT_COUNT * sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&c->d_counters, RT_CNT_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) { delete c; return fail(RT_ERR_DEVICE, std::string("hipMalloc counters: ") + hipGetErrorString(e)); }
-    (void)hipMemset(c->d_counters, 0, RT_CNT_COUNT * sizeof(unsigned long long));
+    (void)hipMemset(c->d_counters, 0, RT_CNT_WORDS * sizeof(unsigned long long));
     *out = c;
     return RT_OK;
 }
@@ -1141,7 +1147,13 @@ int rt_get_counters(rt_context* ctx, uint64_t out[RT_CNT_COUNT]) {
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, ctx->d_counters, RT_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> all(RT_CNT_WORDS);
+    HIP_TRY(hipMemcpy(all.data(), ctx->d_counters, RT_CNT_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < RT_CNT_COUNT; k++) out[k] = all[k];
+    for (uint32_t b = 0; b < RT_CNT_SPREAD; b++) {            // the shading kernel's share of these two, kept in RT_CNT_SPREAD places
+        out[RT_CNT_PATHS] += all[RT_CNT_COUNT + b * RT_CNT_SPREAD_STRIDE];
+        out[RT_CNT_RAYS] += all[RT_CNT_COUNT + b * RT_CNT_SPREAD_STRIDE + 1];
+    }
     return RT_OK;
 }
 
@@ -1159,7 +1171,7 @@ int rt_reset_counters(rt_context* ctx) {
     if (!ctx) return fail(RT_ERR_INVALID, "rt_reset_counters: null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(ctx->d_counters, 0, RT_CNT_COUNT * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(ctx->d_counters, 0, RT_CNT_WORDS * sizeof(uint64_t)));
     timing_collect(ctx);
     for (int k = 0; k < 3; k++) { ctx->time_ms[k] = 0.0; ctx->time_launches[k] = 0; }
     return RT_OK;
