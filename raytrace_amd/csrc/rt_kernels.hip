@@ -257,7 +257,9 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
             depth = -1;
         }
         pools.p0[nxt][pos] = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], dir.x);
-        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(pixel), __int_as_float(sample));
+        // an entry with nothing to trace is marked twice: depth -1 for the shading kernel, pixel -1 for the closest-hit
+        // kernel (which then need not read the third record at all)
+        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(depth > 0 ? pixel : -1), __int_as_float(sample));
         pools.p2[nxt][pos] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(depth));
     }
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
@@ -350,10 +352,9 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
             const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (idx < end) {
                 const float4 a = pools.p0[nxt][idx], b = pools.p1[nxt][idx];
-                const int depth = __float_as_int(pools.p2[nxt][idx].w);
                 ridx = (int)idx;
                 h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-                if (depth > 0) {                   // lanes outside the image carry depth < 0: their hit stays "none"
+                if (__float_as_int(b.z) >= 0) {    // entries with nothing to trace (lanes outside the image) carry pixel -1: their hit stays "none"
                     ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
                     w.begin(sc, r, h, tc);
                 }
