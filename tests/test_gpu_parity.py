@@ -244,6 +244,7 @@ def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
             gpu_ctx.set_option(capi.OPT_WF_BURST, burst)
             gpu_ctx.set_option(capi.OPT_WF_RUN, run)
             gpu_ctx.set_option(capi.OPT_WF_BLOCK, block)
+            gpu_ctx.set_option(capi.OPT_WF_LANES, 2 if block in (256, 1024) else 1)     # two pipelines on two streams: samples split between them
             got, gcnt = p.gpu_render(0, 8, 4)
             assert same_f32(got, ref), (sort, hot, burst, run, vote, refill, block)
             assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2], (sort, hot, burst, run, vote, refill, block)
@@ -253,6 +254,7 @@ def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
         gpu_ctx.set_option(capi.OPT_WF_REFILL, 16)
         gpu_ctx.set_option(capi.OPT_HOT_NODES, 100)
         gpu_ctx.set_option(capi.OPT_WF_BLOCK, 512)
+        gpu_ctx.set_option(capi.OPT_WF_LANES, 1)
         gpu_ctx.set_option(capi.OPT_WF_BURST, 4)
         gpu_ctx.set_option(capi.OPT_WF_RUN, 256)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
