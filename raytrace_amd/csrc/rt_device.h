@@ -453,16 +453,19 @@ __device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& 
             v3 dir = mk3(0.0f, 0.0f, 0.0f);
             bool scattered = true;
             const float dn = vdot(rd, normal);
+            // both diffuse and metal surfaces start with the same draw; one loop serves the lanes of either kind
+            // (two separate loops would each run as long as their slowest lane)
+            v3 rnd = mk3(0.0f, 0.0f, 0.0f);
+            if (mtype == RT_MAT_LAMBERTIAN || mtype == RT_MAT_METAL) rnd = unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k.k0, k.k1);
             if (mtype == RT_MAT_LAMBERTIAN) {
                 v3 d0 = normal;
                 if (dn > 0.0f) d0 = vneg(normal);
-                dir = vnormalize(vadd(d0, unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k.k0, k.k1)));
+                dir = vnormalize(vadd(d0, rnd));
                 const float cos_theta = fabsf(vdot(dir, normal));
                 color = vmul(color, vscale(hit_color, cos_theta));
             } else if (mtype == RT_MAT_METAL) {
                 v3 nn = normal;
                 if (dn > 0.0f) nn = vneg(normal);
-                const v3 rnd = unit_sphere((uint32_t)pixel, (uint32_t)sample, bounce, k.k0, k.k1);
                 if (4.0f * decision < 3.0f + metal_fuzz) {
                     dir = vadd(nn, rnd);
                     const float cos_theta = fabsf(vdot(dir, nn));
