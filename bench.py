@@ -276,7 +276,9 @@ def main():
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, prof = None, {}
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
+        # the committed counter passes were taken on the default workload; they say nothing about another scene or frame size
+        default_workload = args.scene == "formula1" and (args.width, args.height) == (2000, 1200) and args.detail == 1.0 and not args.depth
+        if os.path.exists(tpath) and default_workload:
             try:
                 prof = json.load(open(tpath)).get(kname, {})
                 traffic = prof.get("hbm_bytes_per_launch")
