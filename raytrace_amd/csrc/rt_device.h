@@ -114,14 +114,14 @@ __device__ __forceinline__ void ray_set(RayD& r, v3 o, v3 d) {
     r.i_xy = (f2v){r.ix, r.iy}; r.i_zx = (f2v){r.iz, r.ix}; r.i_yz = (f2v){r.iy, r.iz};
 }
 
-// include/bvh.h:39-58 on a box record as it lies in memory (a = min.x min.y min.z max.x, b = max.y max.z ...).
+// include/bvh.h:39-58 on a box as it lies in memory: three pairs (min.x min.y | min.z max.x | max.y max.z).
 // The per-axis early exit there is equivalent to one final t0 > t1 test because t0 never decreases and t1
 // never increases.  The six subtractions and six multiplications run as three packed pairs each -- lane for
 // lane the same IEEE operations as the scalar form.
-__device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near) {
-    const f2v d0 = (a.xy - r.o_xy) * r.i_xy;      // ax, ay
-    const f2v d1 = (a.zw - r.o_zx) * r.i_zx;      // az, bx
-    const f2v d2 = (b.xy - r.o_yz) * r.i_yz;      // by, bz
+__device__ __forceinline__ bool slab(f2v p0, f2v p1, f2v p2, const RayD& r, float& t_near) {
+    const f2v d0 = (p0 - r.o_xy) * r.i_xy;      // ax, ay
+    const f2v d1 = (p1 - r.o_zx) * r.i_zx;      // az, bx
+    const f2v d2 = (p2 - r.o_yz) * r.i_yz;      // by, bz
     const float ax = d0.x, ay = d0.y, az = d1.x, bx = d1.y, by = d2.x, bz = d2.y;
     const bool nx = r.i_xy.x < 0.0f, ny = r.i_xy.y < 0.0f, nz = r.i_zx.x < 0.0f;
     float t0 = fmaxf(-RT_INF, nx ? bx : ax);
@@ -133,6 +133,7 @@ __device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near)
     t_near = t0;
     return !(t0 > t1) & (t1 > 0.0f);
 }
+__device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near) { return slab(a.xy, a.zw, b.xy, r, t_near); }
 
 struct Hit {
     float t, u, v;
@@ -174,9 +175,9 @@ __device__ __forceinline__ void tri_test(float4 q0, float4 q1, float4 q2, uint32
 #define RT_SPILL_SLOTS 56
 typedef __attribute__((address_space(3))) uint2 lds_uint2;   // explicitly LDS: never merged with the private spill into a flat access
 typedef __attribute__((address_space(3))) f4v lds_float4;   // native vector type: HIP's float4 class cannot be assigned across address spaces
-// LDS copies of hot nodes sit 144 bytes apart (128 + 16): consecutive nodes start 4 banks further on, so lanes that
-// read the same 16-byte piece of different nodes spread over the banks instead of all landing on one bank group.
-#define RT_HOT_STRIDE 144
+// LDS copies of hot nodes hold the 112 bytes a visit reads, back to back: consecutive nodes start 28 banks further
+// on, so lanes that read the same 16-byte piece of different nodes spread over the banks.
+#define RT_HOT_STRIDE 112
 
 struct TravCounters {
     uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node, n_hot_visit, ray_visits, max_ray_visits, n_nonfinite;
@@ -260,15 +261,15 @@ struct Walker {
 
     // visit the two-level node `cur`: one 128-byte record decides up to four grandchildren, slot 0 = visited first
     __device__ __forceinline__ void node_step(const SceneDev& sc, const RayD& r, const Hit& h, TravCounters& tc) {
-        f4v a0, b0, a1, b1, a2, b2, a3, b3;
+        f4v q0, q1, q2, q3, q4, q5, q6;             // the first 112 bytes of the record: 12 pairs of bounds, 4 references
         if (cur < n_hot) {
             const lds_float4* q = hot + cur * (RT_HOT_STRIDE / 16);
-            a0 = q[0]; b0 = q[1]; a1 = q[2]; b1 = q[3]; a2 = q[4]; b2 = q[5]; a3 = q[6]; b3 = q[7];
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
         } else {
             const f4v* q = reinterpret_cast<const f4v*>(sc.nodes + cur);
-            a0 = q[0]; b0 = q[1]; a1 = q[2]; b1 = q[3]; a2 = q[4]; b2 = q[5]; a3 = q[6]; b3 = q[7];
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
         }
-        const uint32_t r0 = __float_as_uint(b0.z), r1 = __float_as_uint(b1.z), r2 = __float_as_uint(b2.z), r3 = __float_as_uint(b3.z);
+        const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
         if (COUNT) {
             tc.n_box += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
             tc.n_node++;
@@ -279,10 +280,10 @@ struct Walker {
         }
         // all four slots are tested without branches: an unused slot costs a few wasted operations, a branch per slot costs more
         float t0, t1, t2, t3;
-        const bool h0 = (r0 != REF_NONE) & slab(a0, b0, r, t0) & !(t0 > h.t);
-        const bool h1 = (r1 != REF_NONE) & slab(a1, b1, r, t1) & !(t1 > h.t);
-        const bool h2 = (r2 != REF_NONE) & slab(a2, b2, r, t2) & !(t2 > h.t);
-        const bool h3 = (r3 != REF_NONE) & slab(a3, b3, r, t3) & !(t3 > h.t);
+        const bool h0 = (r0 != REF_NONE) & slab(q0.xy, q0.zw, q1.xy, r, t0) & !(t0 > h.t);
+        const bool h1 = (r1 != REF_NONE) & slab(q1.zw, q2.xy, q2.zw, r, t1) & !(t1 > h.t);
+        const bool h2 = (r2 != REF_NONE) & slab(q3.xy, q3.zw, q4.xy, r, t2) & !(t2 > h.t);
+        const bool h3 = (r3 != REF_NONE) & slab(q4.zw, q5.xy, q5.zw, r, t3) & !(t3 > h.t);
         // The first hit slot is visited now; later hit slots wait on the stack, last slot deepest.  A slot whose
         // t_near already exceeds the best t is dropped now: the best t only shrinks (upstream would drop it at pop time).
         if (h3 && (h0 || h1 || h2)) push(r3, t3, tc);

@@ -405,13 +405,14 @@ static uint32_t collapse(PackedScene& ps, uint32_t bref, int& need) {
         if (pending > need) need = pending;
     }
     Node4& out = ps.nodes4[me];
+    std::memset(&out, 0, sizeof(out));
     for (int i = 0; i < 4; i++) {
         if (i < used) {
-            out.c[i] = slots[i];
+            for (int a = 0; a < 3; a++) { out.box[i][a] = slots[i].bmin[a]; out.box[i][3 + a] = slots[i].bmax[a]; }
+            out.ref[i] = slots[i].ref;
         } else {
-            for (int a = 0; a < 3; a++) { out.c[i].bmin[a] = INFINITY; out.c[i].bmax[a] = -INFINITY; }
-            out.c[i].ref = REF_NONE;
-            out.c[i].aux = 0;
+            for (int a = 0; a < 3; a++) { out.box[i][a] = INFINITY; out.box[i][3 + a] = -INFINITY; }
+            out.ref[i] = REF_NONE;
         }
     }
     return me;
@@ -430,7 +431,7 @@ static void renumber_breadth_first(PackedScene& ps) {
     for (size_t head = 0; head < order.size(); head++) {
         const Node4& nd = ps.nodes4[order[head]];
         for (int k = 0; k < 4; k++) {
-            const uint32_t r = nd.c[k].ref;
+            const uint32_t r = nd.ref[k];
             if (r == REF_NONE || (r & REF_LEAF)) continue;
             renum[r] = (uint32_t)order.size();
             order.push_back(r);
@@ -440,7 +441,7 @@ static void renumber_breadth_first(PackedScene& ps) {
     for (size_t i = 0; i < order.size(); i++) {
         out[i] = ps.nodes4[order[i]];
         for (int k = 0; k < 4; k++) {
-            uint32_t& r = out[i].c[k].ref;
+            uint32_t& r = out[i].ref[k];
             if (r != REF_NONE && !(r & REF_LEAF)) r = renum[r];
         }
     }
@@ -530,7 +531,7 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
     while (ref != REF_NONE && !(ref & REF_LEAF)) {
         const Node4& n = ps.nodes4[ref];
         uint32_t last = REF_NONE;
-        for (int k = 0; k < 4; k++) if (n.c[k].ref != REF_NONE) last = n.c[k].ref;
+        for (int k = 0; k < 4; k++) if (n.ref[k] != REF_NONE) last = n.ref[k];
         ref = last;
     }
     ps.last_tri = ref == REF_NONE ? REF_NONE : (ref & REF_MASK) + ((ref & REF_PAIR) ? 1u : 0u);

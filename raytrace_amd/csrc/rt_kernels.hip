@@ -301,10 +301,11 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * block);
     const uint32_t count = ctl->count[nxt];
     TravCounters tc = {};
-    for (uint32_t k = threadIdx.x; k < n_hot * 8u; k += block) {
-        const float4 v = reinterpret_cast<const float4*>(sc.nodes)[k];
+    for (uint32_t k = threadIdx.x; k < n_hot * 7u; k += block) {
+        const uint32_t node = k / 7u, piece = k - node * 7u;
+        const float4 v = reinterpret_cast<const float4*>(sc.nodes)[node * 8u + piece];
         f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
-        hot[(k >> 3) * (RT_HOT_STRIDE / 16) + (k & 7u)] = o;
+        hot[node * (RT_HOT_STRIDE / 16) + piece] = o;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;

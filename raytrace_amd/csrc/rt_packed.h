@@ -41,8 +41,13 @@ struct alignas(64) Node64 {
 // the bounds), and the child's t_near never exceeds the grandchild's, so testing the grandchildren
 // directly visits exactly the leaves upstream visits, in the same order -- with half as many
 // dependent fetches per ray.  Unused slots carry ref = REF_NONE.
+// Layout: the four boxes first (six floats each: min.x min.y min.z max.x max.y max.z -- every pair of floats
+// the packed box test works on is 8-byte aligned), then the four references: a visit reads the first 112 bytes,
+// seven 16-byte pieces per lane, not eight.
 struct alignas(128) Node4 {
-    ChildRec c[4];
+    float box[4][6];
+    uint32_t ref[4];
+    uint32_t pad[4];
 };
 
 // Intersection record (48 bytes): v0, e1 = v1 - v0, e2 = v2 - v0 -- the two edge
