@@ -139,7 +139,7 @@ enum {
     RT_OPT_WF_SORT = 10,      /* wavefront: 1 = each shading workgroup files its surviving rays by direction octant (default), 0 = plain order;
                                  scheduling only */
     RT_OPT_TIMING = 11,       /* 1 = bracket every traversal kernel launch with HIP events on the launch stream (see rt_get_timing) */
-    RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 100, 0..512) */
+    RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 128, 0..512) */
     RT_OPT_WF_VOTE = 13,      /* wavefront closest-hit: 0 = fixed pattern (RT_OPT_WF_BURST node trips, then one leaf trip); k > 0 (default 32) = every trip
                                  the wave runs the visit kind most lanes wait for, a leaf visit weighing k/16 node visits; scheduling only */
     RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 16) */

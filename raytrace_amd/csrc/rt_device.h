@@ -305,10 +305,14 @@ struct Walker {
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_leaf++;
         }
         // both records are fetched at once (one memory round trip per leaf visit, not two); the array ends with a spare record
+        // lanes at a one-triangle leaf do not read the second record: every 16-byte piece a lane reads is an L1 access
         const float4* q = reinterpret_cast<const float4*>(sc.isect + p);
-        const float4 a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[3], b1 = q[4], b2 = q[5];
+        const bool pair = (cur & REF_PAIR) != 0;
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2];
+        float4 b0 = a0, b1 = a1, b2 = a2;
+        if (pair) { b0 = q[3]; b1 = q[4]; b2 = q[5]; }
         tri_test(a0, a1, a2, p, r, h);
-        if (cur & REF_PAIR) tri_test(b0, b1, b2, p + 1, r, h);
+        if (pair) tri_test(b0, b1, b2, p + 1, r, h);
         cur = pop(h);
     }
 };

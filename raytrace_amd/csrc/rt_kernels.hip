@@ -629,7 +629,7 @@ struct rt_context {
     int opt_wf_refill = 16;          // vote policy: idle lanes that trigger a refill
     size_t extend_lds_limit = 64 * 1024;   // dynamic LDS the extend kernel may currently be launched with
     int opt_wf_block = 512;          // lanes per workgroup of the extend kernel: three workgroups of eight waves per CU
-    int opt_hot_nodes = 100;         // node records (breadth-first prefix) the extend kernel keeps in LDS
+    int opt_hot_nodes = 128;         // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     int n_cu = 256;                  // compute units of the device
     // The wavefront variant runs up to RT_WF_LANES_MAX independent pipelines ("lanes" of the host loop, nothing to do
