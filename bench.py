@@ -285,9 +285,9 @@ def main():
             except Exception:
                 traffic = None
         # every 16-byte piece a lane loads from memory is one access of the CU's vector L1, which serves about one per
-        # clock; node records the workgroup holds in LDS do not go through it.  Per ray: 8 pieces per node record from
+        # clock; node records the workgroup holds in LDS do not go through it.  Per ray: 7 pieces per node record from
         # memory, 3 per triangle record, 2 for the ray itself and 1 for the hit record written back
-        l1_accesses_per_ray = (8.0 * mix["node_visits_per_ray"] * (1.0 - mix["node_visits_from_lds"]) + 3.0 * mix["tri_tests_per_ray"] + 3.0)
+        l1_accesses_per_ray = (7.0 * mix["node_visits_per_ray"] * (1.0 - mix["node_visits_from_lds"]) + 3.0 * mix["tri_tests_per_ray"] + 3.0)
         out = {
             "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
                       else f"Mrays/s (closest-hit queries), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
