@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle as orc
 from raytrace_amd import capi, scene
-from tests.util import bits, random_rays, same_f32
+from tests.util import bits, random_rays, same_f32, same_f32_or_both_nan
 
 pytestmark = pytest.mark.gpu
 
@@ -73,8 +73,9 @@ class Pair:
         go, gt, gtt, gu, gv = self.gpu_hits(rays)
         assert np.array_equal(go, o), f"{(go != o).sum()} object mismatches of {len(o)}"
         assert np.array_equal(gt, t), f"{(gt != t).sum()} triangle mismatches of {len(t)}"
-        assert same_f32(gtt, tt), f"{(bits(gtt) != bits(tt)).sum()} t mismatches"
-        assert same_f32(gu, u) and same_f32(gv, v)
+        # a NaN ray's t, u, v are NaN on both sides; which NaN is the instruction scheduler's choice (tests/util.py)
+        assert same_f32_or_both_nan(gtt, tt), f"{(bits(gtt) != bits(tt)).sum()} t mismatches"
+        assert same_f32_or_both_nan(gu, u) and same_f32_or_both_nan(gv, v)
         return o
 
 

@@ -11,6 +11,15 @@ def same_f32(a, b):
     return np.array_equal(bits(a), bits(b))
 
 
+def same_f32_or_both_nan(a, b):
+    """Bit-exact float32 equality, except that any NaN equals any NaN.  Sign and payload of a NaN that comes out of
+    arithmetic on NaN operands follow the operand order of the machine instruction, which a compiler is free to
+    swap for commutative operations -- upstream's compiler included -- so they are not part of any contract."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    return a.shape == b.shape and bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+
 def same_triangles(a, b):
     return (np.array_equal(a["material_id"], b["material_id"])
             and all(same_f32(a["v"][f], b["v"][f]) for f in ("position", "normal", "texcoord")))
