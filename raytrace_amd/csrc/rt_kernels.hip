@@ -433,6 +433,7 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
 // range of the next pool with ONE returning atomic -- a returning atomic on a single word sustains only ~90 per
 // microsecond chip-wide, so one per wave (262k per iteration of a 16M-path pool) would cost more than the shading.
 #define RT_SHADE_BLOCK 1024
+static_assert(RT_SHADE_BLOCK == 1024, "wf_shade_kernel's offset scan handles 8 octants x 16 waves = 128 counts, two per lane of wave 0");
 template <bool COUNT>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
     __shared__ uint32_t bin_count[8 * (RT_SHADE_BLOCK / 64)];   // survivors per [direction octant][wave], then their offsets
