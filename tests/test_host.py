@@ -24,6 +24,20 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.rt_abi_version() == 1
 
 
+def test_binding_constants_match_the_header():
+    """Option and counter numbers in the ctypes binding are the header's."""
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rtcore.h")).read()
+    opts = dict(re.findall(r"\bRT_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", text))
+    assert len(opts) >= 16
+    for name, value in opts.items():
+        assert getattr(capi, "OPT_" + name) == int(value), name
+    body = text[text.index("RT_CNT_RAYS"):text.index("RT_CNT_COUNT")]
+    names = re.findall(r"\bRT_CNT_([A-Z0-9_]+)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    for i, name in enumerate(names):
+        assert getattr(capi, "CNT_" + name) == i, name
+    assert capi.CNT_COUNT == int(re.search(r"RT_CNT_COUNT\s*=?\s*(\d+)", text).group(1))
+
+
 def test_pod_layouts_match_upstream_sizes():
     assert capi.TRIANGLE_DTYPE.itemsize == 104 and capi.NODE_DTYPE.itemsize == 36 and capi.MATERIAL_DTYPE.itemsize == 32
     assert capi.TRIANGLE_DTYPE == orc.TRIANGLE_DTYPE and capi.NODE_DTYPE == orc.NODE_DTYPE
