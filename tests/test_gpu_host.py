@@ -65,6 +65,31 @@ def test_bin_main_renders_the_same_picture(tmp_path, batch):
     assert want.std() > 10                                  # a picture, not a constant
 
 
+def test_bin_main_with_a_jpeg_texture(tmp_path):
+    """The textured floor's image file replaced by a JPEG (cv::imread goes by content, not by name; so does the loader
+    here): bin/main's picture equals the Python route's with the pixels libjpeg-turbo decodes from that file."""
+    import glob
+    golden = os.path.join(ROOT, "tests", "golden", "jpeg")
+    pixels = scene_files.read_png_rgb(os.path.join(golden, "photo_420.expect.png"))
+    tex = np.concatenate([pixels[::-1], np.full(pixels.shape[:2] + (1,), 255, dtype=np.uint8)], axis=2)   # stored bottom-up, RGBA
+    asm = scene.material_box(width=64, height=40, n_samples=16)
+    assert len(asm.textures) == 1
+    asm.textures[0] = np.ascontiguousarray(tex)
+    asm.blocks[0].model.mtls[0]["map_Kd"] = asm.textures[0]
+    path = scene_files.write_scene(asm, str(tmp_path / "files"), name="jpegfloor")
+    files = glob.glob(str(tmp_path / "files" / "tex_*.png"))
+    assert len(files) == 1
+    with open(files[0], "wb") as f:
+        f.write(open(os.path.join(golden, "photo_420.jpg"), "rb").read())
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([MAIN, path, str(out), "4"], capture_output=True, text=True, timeout=120, env=dict(os.environ, RT_SEED=str(SEED)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = scene_files.read_png_rgb(str(out / "jpegfloor-output.png"))
+    want = expected_png_pixels(asm, 4, SEED)
+    assert np.array_equal(got, want), f"{(got != want).any(axis=2).sum()} pixels differ"
+
+
 def test_bin_main_usage_and_bad_scene(tmp_path):
     r = subprocess.run([MAIN], capture_output=True, text=True, timeout=30)
     assert r.returncode == 0 and "Usage:" in r.stderr       # csrc/main.cpp:10-13
