@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <queue>
 #include <thread>
 
 namespace rtc {
@@ -418,9 +419,19 @@ static uint32_t collapse(PackedScene& ps, uint32_t bref, int& need) {
     return me;
 }
 
-// Renumber the two-level nodes breadth first from the root: every walk starts at the root, so the nodes nearest
-// to it are by far the most visited, and after this pass they are the first records of the array (kernels can
-// keep a prefix of it close to the lanes).  Visiting order and results do not depend on node numbers.
+// Renumber the two-level nodes from the root.  Every walk starts at the root, so the nodes nearest to it are by
+// far the most visited, and the kernels keep a prefix of the array in LDS.  Which nodes that prefix should hold:
+// the ones a ray is most likely to enter -- for rays without a preferred place or direction that likelihood
+// goes with the surface area of the node's box -- so the first RT_AREA_ORDERED numbers go to the node with the
+// largest box among those whose parent is already numbered (a child's box is never larger than its parent's, so
+// this is the set of the largest boxes); the rest follow breadth first.  Visiting order and results do not depend
+// on node numbers.
+#define RT_AREA_ORDERED 4096
+static double box_area(const float* b) {      // min.xyz, max.xyz
+    const double dx = (double)b[3] - b[0], dy = (double)b[4] - b[1], dz = (double)b[5] - b[2];
+    const double a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : 0.0;
+}
 static void renumber_breadth_first(PackedScene& ps) {
     const size_t n = ps.nodes4.size();
     std::vector<uint32_t> order;            // order[new] = old
@@ -428,7 +439,33 @@ static void renumber_breadth_first(PackedScene& ps) {
     std::vector<uint32_t> renum(n, 0xFFFFFFFFu);
     order.push_back(ps.root.ref);
     renum[ps.root.ref] = 0;
-    for (size_t head = 0; head < order.size(); head++) {
+    // largest box first, while the numbers that matter for the LDS prefix are being given out
+    std::priority_queue<std::pair<double, uint32_t>> open;      // (area, old index) of nodes whose parent is numbered
+    auto offer = [&](uint32_t numbered_old) {
+        const Node4& nd = ps.nodes4[numbered_old];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = nd.ref[k];
+            if (r == REF_NONE || (r & REF_LEAF)) continue;
+            open.push(std::make_pair(box_area(nd.box[k]), r));
+        }
+    };
+    offer(ps.root.ref);
+    while (!open.empty() && order.size() < RT_AREA_ORDERED) {
+        const uint32_t r = open.top().second;
+        open.pop();
+        renum[r] = (uint32_t)order.size();
+        order.push_back(r);
+        offer(r);
+    }
+    // the nodes still waiting, then everything below them, breadth first
+    const size_t head0 = order.size();
+    while (!open.empty()) {
+        const uint32_t r = open.top().second;
+        open.pop();
+        renum[r] = (uint32_t)order.size();
+        order.push_back(r);
+    }
+    for (size_t head = head0; head < order.size(); head++) {
         const Node4& nd = ps.nodes4[order[head]];
         for (int k = 0; k < 4; k++) {
             const uint32_t r = nd.ref[k];
@@ -524,7 +561,14 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
         ps.nodes4.reserve(ps.nodes.size() / 2 + 16);
         ps.root.ref = collapse(ps, ps.root.ref, need);
         ps.max_depth = need;
+        const size_t before = ps.nodes4.size();
         renumber_breadth_first(ps);
+        // every node kept its place in the tree under a new number: a reference out of range would send a kernel out of bounds
+        bool sound = ps.nodes4.size() == before;
+        for (const Node4& nd : ps.nodes4)
+            for (int k = 0; k < 4; k++)
+                if (nd.ref[k] != REF_NONE && !(nd.ref[k] & REF_LEAF) && nd.ref[k] >= ps.nodes4.size()) sound = false;
+        if (!sound) { err = "internal: node renumbering lost a node"; return -1; }
     }
     // The triangle tested last by a walk that enters every box: always the slot visited last, then the leaf's last triangle.
     uint32_t ref = ps.root.ref;
