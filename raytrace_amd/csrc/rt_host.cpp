@@ -359,17 +359,20 @@ struct Packer {
 
 }  // namespace
 
-// Where to cut the object sequence [first, last): `split` (when given) holds the cut chosen for every range, else the middle.
+// Where to cut the object sequence [first, last).  Binary nodes at even depth below the root become two-level
+// nodes (each absorbs its two children), so the best cut of a run depends on the parity of its depth.
 struct TopSplits {
     int n = 0;
-    std::vector<int> cut;                     // cut[first * (n + 1) + last]
-    int at(int first, int last) const { return cut.empty() ? (first + last) / 2 : cut[(size_t)first * (n + 1) + last]; }
+    std::vector<int> cut[2];                  // cut[depth & 1][first * (n + 1) + last]; empty = the middle
+    int at(int first, int last, int depth) const {
+        return cut[0].empty() ? (first + last) / 2 : cut[depth & 1][(size_t)first * (n + 1) + last];
+    }
 };
 
 static ChildRec build_top(PackedScene& ps, const TopSplits& splits, int first, int last, int depth, int& max_depth) {
     if (last - first == 1) return ps.top[first];
     if (depth + 1 > max_depth) max_depth = depth + 1;
-    const int mid = splits.at(first, last);
+    const int mid = splits.at(first, last, depth);
     const uint32_t me = (uint32_t)ps.nodes.size();
     ps.nodes.emplace_back();
     const ChildRec lower = build_top(ps, splits, first, mid, depth + 1, max_depth);
@@ -388,17 +391,20 @@ static ChildRec build_top(PackedScene& ps, const TopSplits& splits, int first, i
 }
 
 // Cuts for the object-level tree.  Any binary tree over contiguous runs of the object sequence keeps upstream's
-// visiting order (the walk takes the lower run first), so the cuts are free to follow the geometry: they minimise the
-// summed surface area of the runs' boxes (the expected number of box tests for rays without a preferred place or
-// direction), by dynamic programming over all runs.  A scene file lists, say, thirty parts of a car, then a ground
-// plane and three lights: cutting in the middle puts half the car into one box with the ground, which every ray
-// that looks down enters.  Falls back to the middle for very many objects or when the tree would become deep.
+// visiting order (the walk takes the lower run first), so the cuts are free to follow the geometry.  A ray enters a
+// node about as often as the surface area of its box says (for rays without a preferred place or direction), and
+// what it pays for is a visit of a two-level node, i.e. of a binary node at even depth; so the cuts minimise the
+// summed box area of the even-depth runs, by dynamic programming over all runs and both parities.  A scene file
+// lists, say, thirty parts of a car, then a ground plane and three lights: cutting in the middle puts half the car
+// into one box with the ground, which every ray that looks down enters.  Falls back to the middle for very many
+// objects or when the tree would become deep.
 static void choose_top_splits(const PackedScene& ps, int n, TopSplits& out) {
     out = TopSplits();
     if (n < 3 || n > 384) return;
     const size_t w = (size_t)n + 1;
-    std::vector<double> area(w * w, 0.0), cost(w * w, 0.0);
-    std::vector<int> cut(w * w, 0), depth(w * w, 0);
+    std::vector<double> area(w * w, 0.0), cost[2] = {std::vector<double>(w * w, 0.0), std::vector<double>(w * w, 0.0)};
+    std::vector<int> cut[2] = {std::vector<int>(w * w, 0), std::vector<int>(w * w, 0)};
+    std::vector<int> depth[2] = {std::vector<int>(w * w, 0), std::vector<int>(w * w, 0)};
     auto finite_area = [](const float* lo, const float* hi) {
         const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
         const double a = dx * dy + dy * dz + dz * dx;
@@ -415,19 +421,23 @@ static void choose_top_splits(const PackedScene& ps, int n, TopSplits& out) {
     for (int len = 2; len <= n; len++)
         for (int i = 0; i + len <= n; i++) {
             const int j = i + len, middle = (i + j) / 2;
-            double best = 1e308;
-            int best_k = middle;
-            for (int k = i + 1; k < j; k++) {
-                const double c = cost[i * w + k] + cost[k * w + j];
-                if (c < best || (c == best && std::abs(k - middle) < std::abs(best_k - middle))) { best = c; best_k = k; }
+            for (int parity = 0; parity < 2; parity++) {          // parity of this run's depth; its parts are one deeper
+                const std::vector<double>& below = cost[parity ^ 1];
+                double best = 1e308;
+                int best_k = middle;
+                for (int k = i + 1; k < j; k++) {
+                    const double c = below[i * w + k] + below[k * w + j];
+                    if (c < best || (c == best && std::abs(k - middle) < std::abs(best_k - middle))) { best = c; best_k = k; }
+                }
+                cost[parity][i * w + j] = (parity == 0 ? area[i * w + j] : 0.0) + best;
+                cut[parity][i * w + j] = best_k;
+                depth[parity][i * w + j] = 1 + std::max(depth[parity ^ 1][i * w + best_k], depth[parity ^ 1][best_k * w + j]);
             }
-            cost[i * w + j] = area[i * w + j] + best;
-            cut[i * w + j] = best_k;
-            depth[i * w + j] = 1 + std::max(depth[i * w + best_k], depth[best_k * w + j]);
         }
-    if (depth[0 * w + n] > 24) return;
+    if (depth[0][0 * w + n] > 24) return;
     out.n = n;
-    out.cut.swap(cut);
+    out.cut[0].swap(cut[0]);
+    out.cut[1].swap(cut[1]);
 }
 
 // Collapse the binary node `bref` and its two children into one Node4; returns its index.
