@@ -129,7 +129,7 @@ enum {
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
     RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 1024, fewer when the
                                  buffer would pass 64 GiB); scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
-    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 9); deeper levels spill to private memory */
+    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 10); deeper levels spill to private memory */
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
                                  In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
@@ -139,7 +139,7 @@ enum {
     RT_OPT_WF_SORT = 10,      /* wavefront: 1 = each shading workgroup files its surviving rays by direction octant (default), 0 = plain order;
                                  scheduling only */
     RT_OPT_TIMING = 11,       /* 1 = bracket every traversal kernel launch with HIP events on the launch stream (see rt_get_timing) */
-    RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 128, 0..512) */
+    RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 100, 0..512) */
     RT_OPT_WF_VOTE = 13,      /* wavefront closest-hit: 0 = fixed pattern (RT_OPT_WF_BURST node trips, then one leaf trip); k > 0 (default 32) = every trip
                                  the wave runs the visit kind most lanes wait for, a leaf visit weighing k/16 node visits; scheduling only */
     RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 16) */
