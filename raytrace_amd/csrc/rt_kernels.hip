@@ -180,10 +180,11 @@ __global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int f
 //   generate : append that many new camera paths, in tile order, so fresh primary rays fill whole waves;
 //   extend   : closest hit for every pooled path.
 // Every stage runs with full waves and few registers; the price is ~200 B of state traffic per segment.
+#define RT_FRESH_PATH 0x80000000u   // in the sample word of a pool entry: a path that has not been shaded yet
 struct WfPools {
     float4* p0[2];      // origin.xyz, dir.x
-    float4* p1[2];      // dir.y, dir.z, pixel, sample (bit patterns)
-    float4* p2[2];      // color.rgb, depth left (int bits; < 0 marks a lane outside the image)
+    float4* p1[2];      // dir.y, dir.z, pixel (-1: nothing to trace), sample | RT_FRESH_PATH (bit patterns)
+    float4* p2[2];      // color.rgb, depth left (int bits); not stored for new paths
     float4* hit;        // t, u, v, packed triangle (written by extend for the pool it ran on)
 };
 
@@ -257,10 +258,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
             depth = -1;
         }
         pools.p0[nxt][pos] = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], dir.x);
-        // an entry with nothing to trace is marked twice: depth -1 for the shading kernel, pixel -1 for the closest-hit
-        // kernel (which then need not read the third record at all)
-        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(depth > 0 ? pixel : -1), __int_as_float(sample));
-        pools.p2[nxt][pos] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(depth));
+        // an entry with nothing to trace carries pixel -1: neither the closest-hit kernel nor the shading kernel looks further
+        // the sample word's top bit says "new path": its third record (throughput 1, full depth) is implied, neither
+        // written here nor read by the shading kernel
+        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(depth > 0 ? pixel : -1), __uint_as_float((uint32_t)sample | RT_FRESH_PATH));
     }
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
@@ -445,10 +446,14 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     bool survives = false;
     float4 o0, o1, o2;
     if (i < ctl->count[cur]) {
-        const float4 a = pools.p0[cur][i], b = pools.p1[cur][i], c = pools.p2[cur][i], hq = pools.hit[i];
-        int depth = __float_as_int(c.w);
-        if (depth > 0) {
-            const int pixel = __float_as_int(b.z), sample = __float_as_int(b.w);
+        const float4 a = pools.p0[cur][i], b = pools.p1[cur][i], hq = pools.hit[i];
+        const int pixel = __float_as_int(b.z);
+        if (pixel >= 0) {                                            // -1: nothing was traced for this entry
+            const uint32_t sample_word = __float_as_uint(b.w);
+            const int sample = (int)(sample_word & ~RT_FRESH_PATH);
+            float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
+            if (!(sample_word & RT_FRESH_PATH)) c = pools.p2[cur][i];   // a new path's third record is implied
+            int depth = __float_as_int(c.w);
             depth--;                                                 // the segment extend just traced (raytrace.cu:213)
             n_rays = 1;
             ShadeConst sk;
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             } else {
                 survives = true;
                 o0 = make_float4(ray.ox, ray.oy, ray.oz, ray.dx);
-                o1 = make_float4(ray.dy, ray.dz, b.z, b.w);
+                o1 = make_float4(ray.dy, ray.dz, b.z, __int_as_float(sample));
                 o2 = make_float4(color.x, color.y, color.z, __int_as_float(depth));
             }
         }
