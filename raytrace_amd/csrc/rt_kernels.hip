@@ -180,10 +180,13 @@ __global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int f
 //   generate : append that many new camera paths, in tile order, so fresh primary rays fill whole waves;
 //   extend   : closest hit for every pooled path.
 // Every stage runs with full waves and few registers; the price is ~200 B of state traffic per segment.
-#define RT_FRESH_PATH 0x80000000u   // in the sample word of a pool entry: a path that has not been shaded yet
+// Pool entry: three 16-byte records.  A new path has only the first: its origin is the camera, its sample index follows from
+// its place in the refill, its throughput is 1 and its depth the full depth.
+#define RT_FRESH_PATH 0x40000000u   // in the pixel word: a path that has not been shaded yet
+#define RT_PIXEL_MASK 0x3FFFFFFFu
 struct WfPools {
-    float4* p0[2];      // origin.xyz, dir.x
-    float4* p1[2];      // dir.y, dir.z, pixel (-1: nothing to trace), sample | RT_FRESH_PATH (bit patterns)
+    float4* p0[2];      // dir.xyz, pixel word: pixel | RT_FRESH_PATH, or -1 when there is nothing to trace
+    float4* p1[2];      // origin.xyz, sample (int bits); not stored for new paths
     float4* p2[2];      // color.rgb, depth left (int bits); not stored for new paths
     float4* hit;        // t, u, v, packed triangle (written by extend for the pool it ran on)
 };
@@ -195,13 +198,14 @@ struct WfCtl {
     uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
-    uint32_t pad[2];
+    uint32_t gen_rem;               // path id of the refill's first path, modulo the paths per tile
+    uint32_t pad;
     // closest-hit launch under RT_OPT_COUNTERS: earliest wave start, latest wave end, sum of wave ends (100 MHz ticks), waves that did work
     unsigned long long t_first, t_last, t_end_sum, n_worked;
     uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per region, first entry no wave has claimed yet (one cache line each)
 };
 
-__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity, unsigned long long* counters) {
+__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity, uint32_t per_tile, unsigned long long* counters) {
     if (threadIdx.x || blockIdx.x) return;
     if (ctl->n_worked) {
         // fold the previous closest-hit launch's wave times: slot-ticks the launch spanned, and those left idle behind waves that ended early
@@ -216,6 +220,7 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
     ctl->gen_base = have;
     ctl->gen_count = n;
     ctl->gen_first = ctl->cursor;
+    ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
     ctl->cursor += n;
     ctl->count[nxt] = have + n;
     ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
@@ -257,11 +262,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
         } else {
             depth = -1;
         }
-        pools.p0[nxt][pos] = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], dir.x);
-        // an entry with nothing to trace carries pixel -1: neither the closest-hit kernel nor the shading kernel looks further
-        // the sample word's top bit says "new path": its third record (throughput 1, full depth) is implied, neither
-        // written here nor read by the shading kernel
-        pools.p1[nxt][pos] = make_float4(dir.y, dir.z, __int_as_float(depth > 0 ? pixel : -1), __uint_as_float((uint32_t)sample | RT_FRESH_PATH));
+        pools.p0[nxt][pos] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth > 0 ? ((uint32_t)pixel | RT_FRESH_PATH) : 0xFFFFFFFFu));
     }
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 template <bool COUNT>
 __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
-                                                             int vote_leaf_weight, int refill_min,
+                                                             int vote_leaf_weight, int refill_min, float cam_x, float cam_y, float cam_z,
                                                              unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
@@ -353,11 +354,14 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
         if (idle) {
             const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (idx < end) {
-                const float4 a = pools.p0[nxt][idx], b = pools.p1[nxt][idx];
+                const float4 a = pools.p0[nxt][idx];
+                const uint32_t word = __float_as_uint(a.w);
                 ridx = (int)idx;
                 h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-                if (__float_as_int(b.z) >= 0) {    // entries with nothing to trace (lanes outside the image) carry pixel -1: their hit stays "none"
-                    ray_set(r, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y));
+                if ((int)word >= 0) {              // entries with nothing to trace (lanes outside the image) carry -1: their hit stays "none"
+                    v3 origin = mk3(cam_x, cam_y, cam_z);                 // a new path starts at the camera and has no second record
+                    if (!(word & RT_FRESH_PATH)) { const float4 b = pools.p1[nxt][idx]; origin = mk3(b.x, b.y, b.z); }
+                    ray_set(r, origin, mk3(a.x, a.y, a.z));
                     w.begin(sc, r, h, tc);
                 }
             }
@@ -446,13 +450,23 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     bool survives = false;
     float4 o0, o1, o2;
     if (i < ctl->count[cur]) {
-        const float4 a = pools.p0[cur][i], b = pools.p1[cur][i], hq = pools.hit[i];
-        const int pixel = __float_as_int(b.z);
-        if (pixel >= 0) {                                            // -1: nothing was traced for this entry
-            const uint32_t sample_word = __float_as_uint(b.w);
-            const int sample = (int)(sample_word & ~RT_FRESH_PATH);
+        const float4 a = pools.p0[cur][i], hq = pools.hit[i];
+        const uint32_t word = __float_as_uint(a.w);
+        if ((int)word >= 0) {                                        // -1: nothing was traced for this entry
+            const int pixel = (int)(word & RT_PIXEL_MASK);
+            // a new path: origin, sample, throughput and depth are implied (its sample index follows from its place in the
+            // refill, as wf_generate_kernel counted it out); any other path: second and third record
+            float4 b = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], 0.0f);
             float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
-            if (!(sample_word & RT_FRESH_PATH)) c = pools.p2[cur][i];   // a new path's third record is implied
+            int sample;
+            if (word & RT_FRESH_PATH) {
+                const uint32_t rem = ctl->gen_rem + (i - ctl->gen_base);
+                sample = pp.first_sample + (int)((rem % ((uint32_t)pp.n_samples * 256u)) >> 8);
+            } else {
+                b = pools.p1[cur][i];
+                c = pools.p2[cur][i];
+                sample = __float_as_int(b.w);
+            }
             int depth = __float_as_int(c.w);
             depth--;                                                 // the segment extend just traced (raytrace.cu:213)
             n_rays = 1;
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
             sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
             RayD ray;
-            ray.ox = a.x; ray.oy = a.y; ray.oz = a.z; ray.dx = a.w; ray.dy = b.x; ray.dz = b.y;
+            ray.ox = b.x; ray.oy = b.y; ray.oz = b.z; ray.dx = a.x; ray.dy = a.y; ray.dz = a.z;
             ray.ix = ray.iy = ray.iz = 0.0f;                         // shading never reads the inverses
             Hit h;
             h.t = hq.x; h.u = hq.y; h.v = hq.z; h.tri = __float_as_uint(hq.w);
@@ -478,8 +492,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
                 slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
             } else {
                 survives = true;
-                o0 = make_float4(ray.ox, ray.oy, ray.oz, ray.dx);
-                o1 = make_float4(ray.dy, ray.dz, b.z, __int_as_float(sample));
+                o0 = make_float4(ray.dx, ray.dy, ray.dz, __int_as_float(pixel));
+                o1 = make_float4(ray.ox, ray.oy, ray.oz, __int_as_float(sample));
                 o2 = make_float4(color.x, color.y, color.z, __int_as_float(depth));
             }
         }
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     // atomic per workgroup.  With pp.sort_rays == 0 every survivor is filed under octant 0: plain order.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t oct = 0;
-    if (survives && pp.sort_rays) oct = (o0.w < 0.0f ? 1u : 0u) | (o1.x < 0.0f ? 2u : 0u) | (o1.y < 0.0f ? 4u : 0u);
+    if (survives && pp.sort_rays) oct = (o0.x < 0.0f ? 1u : 0u) | (o0.y < 0.0f ? 2u : 0u) | (o0.z < 0.0f ? 4u : 0u);
     uint32_t rank = 0;
     for (uint32_t o = 0; o < 8u; o++) {
         const unsigned long long m = __ballot(survives && oct == o);
@@ -1013,15 +1027,15 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                 else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, R.pp);
                 timing_end(ctx, tk, ls);
             }
-            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, ls, L.d_ctl, nxt, R.total, cap, ctx->d_counters);
+            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, ls, L.d_ctl, nxt, R.total, cap, (uint32_t)R.pp.n_samples * 256u, ctx->d_counters);
             hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, R.pp);
             const int tke = timing_begin(ctx, 0, ls);
             if (ctx->opt_counters)
                 hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
-                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
+                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2], ctx->d_counters);
             else
                 hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
-                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, ctx->d_counters);
+                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2], ctx->d_counters);
             timing_end(ctx, tke, ls);
             HIP_TRY(hipGetLastError());
             R.cur = nxt;
@@ -1059,6 +1073,7 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     if (first_sample % semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: first_sample must be a multiple of semantic_batch");
     if ((long long)first_sample + spp > 0x7FFFFFFFLL - semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: sample index overflow");
     if (spp == 0) return RT_OK;
+    if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, "rt_raytrace: more than 2^30-1 pixels");
     if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, "rt_raytrace: BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
