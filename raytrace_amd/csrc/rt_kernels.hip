@@ -198,8 +198,8 @@ struct WfCtl {
     uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
-    uint32_t gen_rem;               // path id of the refill's first path, modulo the paths per tile
-    uint32_t pad;
+    uint32_t gen_rem;               // path id of the refill's first path, modulo the paths per tile ...
+    uint32_t gen_tile;              // ... and divided by them: the tile the refill starts in
     // closest-hit launch under RT_OPT_COUNTERS: earliest wave start, latest wave end, sum of wave ends (100 MHz ticks), waves that did work
     unsigned long long t_first, t_last, t_end_sum, n_worked;
     uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per region, first entry no wave has claimed yet (one cache line each)
@@ -221,6 +221,7 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
     ctl->gen_count = n;
     ctl->gen_first = ctl->cursor;
     ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
+    ctl->gen_tile = (uint32_t)(ctl->cursor / per_tile);
     ctl->cursor += n;
     ctl->count[nxt] = have + n;
     ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
@@ -230,13 +231,17 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
 // Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
 // tile's next sample, then the next tile, so consecutive waves trace neighbouring primary rays.
 __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __restrict__ ctl, WfPools pools, int nxt, PathParams pp) {
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
     uint32_t n_paths = 0;
-    if (j < ctl->gen_count) {
-        const unsigned long long id = ctl->gen_first + j;
+    // the grid is sized for the chip, not for the pool (half a million workgroups of which most find nothing to do cost
+    // more than the writing): a workgroup strides over the new paths
+    const uint32_t gen_count = ctl->gen_count;
+    for (uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x; j < gen_count; j += gridDim.x * RT_BLOCK) {
+        // path id = gen_first + j, taken apart with 32-bit arithmetic: the planner has divided the first id already
         const uint32_t per_tile = (uint32_t)pp.n_samples * 256u;
-        const uint32_t tile = (uint32_t)(id / per_tile);
-        const uint32_t rem = (uint32_t)(id - (unsigned long long)tile * per_tile);
+        const uint32_t along = ctl->gen_rem + j;            // below 2^32: per_tile <= 2^31 and j < 2^28
+        const uint32_t over = along / per_tile;
+        const uint32_t tile = ctl->gen_tile + over;
+        const uint32_t rem = along - over * per_tile;
         const uint32_t s = rem >> 8, p = rem & 255u;
         const int tx = tile % pp.tiles_x, ty = tile / pp.tiles_x;
         const int wave = p >> 6, lane = p & 63;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
                 float* slot = pp.slots + ((size_t)s * (size_t)pp.n_pixel + (size_t)pixel) * 3;
                 slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
                 depth = -1;
-                n_paths = 1;
+                n_paths++;
             }
         } else {
             depth = -1;
@@ -1009,7 +1014,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         HIP_TRY(hipStreamWaitEvent(L.stream, ctx->fork_ev, 0));
         HIP_TRY(hipMemsetAsync(L.d_ctl, 0, sizeof(WfCtl), L.stream));
     }
-    const dim3 grid(cap / RT_BLOCK), block(RT_BLOCK);
+    const dim3 grid(std::min<uint32_t>(cap / RT_BLOCK, (uint32_t)ctx->n_cu * 64u)), block(RT_BLOCK);
     const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
     // one launch fills the chip once; the waves share out the pool themselves
     const uint32_t wanted = (cap + rpb * (eb / 64) - 1) / (rpb * (eb / 64));
