@@ -129,7 +129,7 @@ enum {
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
     RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 1024, fewer when the
                                  buffer would pass 64 GiB); scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
-    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 10); deeper levels spill to private memory */
+    RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 11); deeper levels spill to private memory */
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
                                  In wavefront mode rt_raytrace waits on the stream while it drives the stages. */
@@ -143,7 +143,7 @@ enum {
     RT_OPT_WF_VOTE = 13,      /* wavefront closest-hit: 0 = fixed pattern (RT_OPT_WF_BURST node trips, then one leaf trip); k > 0 (default 32) = every trip
                                  the wave runs the visit kind most lanes wait for, a leaf visit weighing k/16 node visits; scheduling only */
     RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 16) */
-    RT_OPT_WF_BLOCK = 15,     /* wavefront closest-hit: lanes per workgroup (default 512; a multiple of 64 up to 1024); scheduling only */
+    RT_OPT_WF_BLOCK = 15,     /* wavefront closest-hit: lanes per workgroup (default 768; a multiple of 64 up to 1024); scheduling only */
     RT_OPT_WF_LANES = 16,     /* wavefront: independent pipelines a pass's samples are split over, each on a stream of its own, so that
                                  one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);
                                  scheduling only */

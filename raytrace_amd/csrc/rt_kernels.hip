@@ -637,7 +637,7 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
-    int opt_lds_slots = 10;          // stack levels kept in LDS (deeper ones spill to private memory)
+    int opt_lds_slots = 11;          // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 1024;             // samples per pixel held in the slot buffer at once (less when that would exceed RT_SLOTS_MAX_BYTES)
     int opt_timing = 0;              // record HIP events around the traversal kernels
@@ -653,7 +653,7 @@ struct rt_context {
     int opt_wf_vote = 32;            // 0 = fixed node burst; k > 0 = per-trip vote, a leaf visit weighs k/16 node visits
     int opt_wf_refill = 16;          // vote policy: idle lanes that trigger a refill
     size_t extend_lds_limit = 64 * 1024;   // dynamic LDS the extend kernel may currently be launched with
-    int opt_wf_block = 512;          // lanes per workgroup of the extend kernel: three workgroups of eight waves per CU
+    int opt_wf_block = 768;          // lanes per workgroup of the extend kernel: two workgroups of twelve waves per CU
     int opt_hot_nodes = 100;         // node records (breadth-first prefix) the extend kernel keeps in LDS
     int opt_wf_burst = 4;            // inner-node trips between two looks at leaves / idle lanes
     int n_cu = 256;                  // compute units of the device

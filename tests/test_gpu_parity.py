@@ -254,7 +254,7 @@ def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
         gpu_ctx.set_option(capi.OPT_WF_VOTE, 32)
         gpu_ctx.set_option(capi.OPT_WF_REFILL, 16)
         gpu_ctx.set_option(capi.OPT_HOT_NODES, 100)
-        gpu_ctx.set_option(capi.OPT_WF_BLOCK, 512)
+        gpu_ctx.set_option(capi.OPT_WF_BLOCK, 768)
         gpu_ctx.set_option(capi.OPT_WF_LANES, 1)
         gpu_ctx.set_option(capi.OPT_WF_BURST, 4)
         gpu_ctx.set_option(capi.OPT_WF_RUN, 256)
