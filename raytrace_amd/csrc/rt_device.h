@@ -205,9 +205,15 @@ struct Walker {
     __device__ __forceinline__ void set_hot(lds_float4* hot_, uint32_t n_hot_) { hot = hot_; n_hot = n_hot_; }
 
     __device__ __forceinline__ void begin(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) {
-        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
         sp = 0;
-        cur = REF_NONE;
+        cur = first_ref(sc, r, h, tc);
+    }
+
+    // Start of the walk for ray `r`: resets `h` and returns what the walk visits first (REF_NONE: nothing).  Touches no
+    // walker state, so a caller can keep its own walk going in the lanes that take no new ray.
+    __device__ __forceinline__ uint32_t first_ref(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) const {
+        h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
+        uint32_t first = REF_NONE;
         float tn;
         if (COUNT) {
             tc.n_box++;
@@ -232,7 +238,8 @@ struct Walker {
                 const float4* q = reinterpret_cast<const float4*>(sc.isect + sc.last_tri);
                 tri_test(q[0], q[1], q[2], sc.last_tri, r, h);
             }
-        } else if (!still && slab(a, b, r, tn)) cur = sc.root.ref;
+        } else if (!still && slab(a, b, r, tn)) first = sc.root.ref;
+        return first;
     }
 
     // next deferred sibling whose t_near does not exceed the best t (upstream tests this at pop time, raytrace.cu:55)

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 // Which visit the wave runs next: `vote_leaf_weight` == 0 -> at most `node_burst` node trips, then one leaf trip;
 // k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
 // lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
-template <bool COUNT>
+template <bool COUNT, bool VOTE>
 __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
                                                              int vote_leaf_weight, int refill_min, float cam_x, float cam_y, float cam_z,
@@ -379,34 +379,47 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
             }
             if (!got) { exhausted = true; return; }
         }
-        if (idle) {
-            const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (idx < end) {
-                const float4 a = pools.p0[nxt][idx];
-                const uint32_t word = __float_as_uint(a.w);
-                ridx = (int)idx;
-                h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
-                if ((int)word >= 0) {              // entries with nothing to trace (lanes outside the image) carry -1: their hit stays "none"
-                    v3 origin = mk3(cam_x, cam_y, cam_z);                 // a new path starts at the camera and has no second record
-                    if (!(word & RT_FRESH_PATH)) { const float4 b = pools.p1[nxt][idx]; origin = mk3(b.x, b.y, b.z); }
-                    ray_set(r, origin, mk3(a.x, a.y, a.z));
-                    w.begin(sc, r, h, tc);
-                }
-            }
+        // The lanes that take a new ray get it through selects at the end, not by assignments inside the branch: the ray and
+        // the walk state then have one home register each for the whole trip loop (assigned in a branch, the new values
+        // would live beside the old ones and every trip would end with some forty register copies).
+        const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const bool take = idle && idx < end;
+        float4 a = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(0xFFFFFFFFu));
+        float4 b = make_float4(cam_x, cam_y, cam_z, 0.0f);          // a new path starts at the camera and has no second record
+        if (take) {
+            a = pools.p0[nxt][idx];
+            if (!(__float_as_uint(a.w) & RT_FRESH_PATH)) b = pools.p1[nxt][idx];
         }
+        // entries with nothing to trace (lanes outside the image) carry -1: their hit stays "none"
+        const bool trace = take && (int)__float_as_uint(a.w) >= 0;
+        RayD rn;
+        ray_set(rn, mk3(b.x, b.y, b.z), mk3(a.x, a.y, a.z));
+        Hit hn;
+        hn.t = RT_INF; hn.u = 0.0f; hn.v = 0.0f; hn.tri = REF_NONE;
+        uint32_t first = REF_NONE;
+        if (trace) first = w.first_ref(sc, rn, hn, tc);
+        ridx = take ? (int)idx : ridx;
+        h.t = take ? hn.t : h.t; h.u = take ? hn.u : h.u; h.v = take ? hn.v : h.v; h.tri = take ? hn.tri : h.tri;
+        w.cur = trace ? first : w.cur;
+        w.sp = trace ? 0 : w.sp;
+        r.ox = trace ? rn.ox : r.ox; r.oy = trace ? rn.oy : r.oy; r.oz = trace ? rn.oz : r.oz;
+        r.dx = trace ? rn.dx : r.dx; r.dy = trace ? rn.dy : r.dy; r.dz = trace ? rn.dz : r.dz;
+        r.ix = trace ? rn.ix : r.ix; r.iy = trace ? rn.iy : r.iy; r.iz = trace ? rn.iz : r.iz;
+        r.o_xy = trace ? rn.o_xy : r.o_xy; r.o_zx = trace ? rn.o_zx : r.o_zx; r.o_yz = trace ? rn.o_yz : r.o_yz;
+        r.i_xy = trace ? rn.i_xy : r.i_xy; r.i_zx = trace ? rn.i_zx : r.i_zx; r.i_yz = trace ? rn.i_yz : r.i_yz;
         next = min(end, next + (uint32_t)__popcll(m));
     };
     unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0;
     const unsigned long long cyc_begin = COUNT ? clock64() : 0ull;
     const unsigned long long tick_begin = COUNT ? wall_clock64() : 0ull;
-    for (;;) {
-        const bool idle = w.done();
-        if (idle && ridx >= 0) {
-            pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
-            ridx = -1;
-        }
-        const unsigned long long m = __ballot(idle);
-        if (vote_leaf_weight == 0) {
+    if (!VOTE) {
+        for (;;) {
+            const bool idle = w.done();
+            if (idle && ridx >= 0) {
+                pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                ridx = -1;
+            }
+            const unsigned long long m = __ballot(idle);
             if (m && !exhausted) refill(m, idle);
             if (!__any(ridx >= 0)) {
                 if (exhausted) break;              // nothing in flight and nothing left to claim
@@ -418,25 +431,39 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
                 if (--burst == 0) break;
             }
             if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
-        } else {
-            const int n_node = __popcll(__ballot(w.at_inner())), n_leaf = __popcll(__ballot(w.at_leaf()));
-            if (m && !exhausted && ((int)__popcll(m) >= refill_min || n_node + n_leaf == 0)) {
+        }
+    } else {
+        // Two loops, so that the rays sit still in their registers while the wave walks: the outer one hands in finished
+        // rays and takes new ones, the inner one runs trips until a refill is due (or nothing is left to visit).
+        bool running = true;                       // wave-uniform
+        while (running) {
+            const bool idle = w.done();
+            if (idle && ridx >= 0) {
+                pools.hit[ridx] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                ridx = -1;
+            }
+            const unsigned long long m = __ballot(idle);
+            const bool any_walking = __any(!idle);
+            if (m && !exhausted && ((int)__popcll(m) >= refill_min || !any_walking)) {
                 const unsigned long long t0 = COUNT ? clock64() : 0ull;
                 refill(m, idle);
                 if (COUNT) cyc_refill += clock64() - t0;
-                continue;                          // count again: the new rays may be anywhere
+            } else if (!any_walking) {
+                running = false;                   // every lane has handed in its ray and there is nothing left to claim
             }
-            if (n_node + n_leaf == 0) {
-                if (__any(ridx >= 0)) continue;    // rays that ended at once (missed the root box): store them next trip
-                break;
-            }
-            const unsigned long long t0 = COUNT ? clock64() : 0ull;
-            if (n_node * 16 >= n_leaf * vote_leaf_weight) {
-                if (w.at_inner()) w.node_step(sc, r, h, tc);
-                if (COUNT) cyc_node += clock64() - t0;
-            } else {
-                if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
-                if (COUNT) cyc_leaf += clock64() - t0;
+            for (;;) {
+                const int n_idle = __popcll(__ballot(w.done()));
+                const int n_node = __popcll(__ballot(w.at_inner())), n_leaf = __popcll(__ballot(w.at_leaf()));
+                if (n_node + n_leaf == 0) break;                       // rays that ended at once are handed in above
+                if (!exhausted && n_idle >= refill_min) break;         // a refill is due
+                const unsigned long long t0 = COUNT ? clock64() : 0ull;
+                if (n_node * 16 >= n_leaf * vote_leaf_weight) {
+                    if (w.at_inner()) w.node_step(sc, r, h, tc);
+                    if (COUNT) cyc_node += clock64() - t0;
+                } else {
+                    if (w.at_leaf()) w.leaf_step(sc, r, h, tc);
+                    if (COUNT) cyc_leaf += clock64() - t0;
+                }
             }
         }
     }
@@ -1007,8 +1034,10 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE;
     if (elds > ctx->extend_lds_limit) {               // more than the default 64 KB of dynamic LDS has to be asked for once
         if (elds > 160u * 1024u) return fail(RT_ERR_INVALID, "rt_raytrace: stack slots and hot nodes need more than 160 KB of LDS per workgroup");
-        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
-        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
+        HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
         ctx->extend_lds_limit = elds;
     }
     // the pipelines start after the work already queued on the caller's stream and hand back to it at the end
@@ -1058,12 +1087,13 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, ls, L.d_ctl, nxt, R.total, cap, (uint32_t)R.pp.n_samples * 256u, ctx->d_counters);
             hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, R.pp);
             const int tke = timing_begin(ctx, 0, ls);
-            if (ctx->opt_counters)
-                hipLaunchKernelGGL(wf_extend_kernel<true>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
+            {
+                // four builds of one kernel: with or without the counters, with the per-trip vote or the fixed node burst
+                auto kernel = ctx->opt_counters ? (ctx->opt_wf_vote ? wf_extend_kernel<true, true> : wf_extend_kernel<true, false>)
+                                                : (ctx->opt_wf_vote ? wf_extend_kernel<false, true> : wf_extend_kernel<false, false>);
+                hipLaunchKernelGGL(kernel, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
                                    slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2], ctx->d_counters);
-            else
-                hipLaunchKernelGGL(wf_extend_kernel<false>, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
-                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2], ctx->d_counters);
+            }
             timing_end(ctx, tke, ls);
             HIP_TRY(hipGetLastError());
             R.cur = nxt;
