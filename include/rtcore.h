@@ -142,7 +142,7 @@ enum {
     RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 100, 0..512) */
     RT_OPT_WF_VOTE = 13,      /* wavefront closest-hit: 0 = fixed pattern (RT_OPT_WF_BURST node trips, then one leaf trip); k > 0 (default 32) = every trip
                                  the wave runs the visit kind most lanes wait for, a leaf visit weighing k/16 node visits; scheduling only */
-    RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 16) */
+    RT_OPT_WF_REFILL = 14,    /* with RT_OPT_WF_VOTE: idle lanes per wave that trigger a refill from the pool (default 24) */
     RT_OPT_WF_BLOCK = 15,     /* wavefront closest-hit: lanes per workgroup (default 768; a multiple of 64 up to 1024); scheduling only */
     RT_OPT_WF_LANES = 16,     /* wavefront: independent pipelines a pass's samples are split over, each on a stream of its own, so that
                                  one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);

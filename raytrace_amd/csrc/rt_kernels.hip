@@ -701,7 +701,7 @@ struct rt_context {
     int opt_wf_run = 256;            // pool entries a closest-hit wave claims from the queue at a time
     int opt_wf_sort = 1;             // shade kernel files surviving rays by direction octant
     int opt_wf_vote = 32;            // 0 = fixed node burst; k > 0 = per-trip vote, a leaf visit weighs k/16 node visits
-    int opt_wf_refill = 16;          // vote policy: idle lanes that trigger a refill
+    int opt_wf_refill = 24;          // vote policy: idle lanes that trigger a refill
     size_t extend_lds_limit = 64 * 1024;   // dynamic LDS the extend kernel may currently be launched with
     int opt_wf_block = 768;          // lanes per workgroup of the extend kernel: two workgroups of twelve waves per CU
     int opt_hot_nodes = 100;         // node records (breadth-first prefix) the extend kernel keeps in LDS

@@ -252,7 +252,7 @@ def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
     finally:
         gpu_ctx.set_option(capi.OPT_WF_SORT, 1)
         gpu_ctx.set_option(capi.OPT_WF_VOTE, 32)
-        gpu_ctx.set_option(capi.OPT_WF_REFILL, 16)
+        gpu_ctx.set_option(capi.OPT_WF_REFILL, 24)
         gpu_ctx.set_option(capi.OPT_HOT_NODES, 100)
         gpu_ctx.set_option(capi.OPT_WF_BLOCK, 768)
         gpu_ctx.set_option(capi.OPT_WF_LANES, 1)
