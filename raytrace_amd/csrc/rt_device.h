@@ -316,7 +316,8 @@ struct Walker {
         const float4* q = reinterpret_cast<const float4*>(sc.isect + p);
         const bool pair = (cur & REF_PAIR) != 0;
         const float4 a0 = q[0], a1 = q[1], a2 = q[2];
-        float4 b0 = a0, b1 = a1, b2 = a2;
+        // left unset without a second triangle: a default taken from the first record would make the second fetch wait for the first
+        float4 b0, b1, b2;
         if (pair) { b0 = q[3]; b1 = q[4]; b2 = q[5]; }
         tri_test(a0, a1, a2, p, r, h);
         if (pair) tri_test(b0, b1, b2, p + 1, r, h);
