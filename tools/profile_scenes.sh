@@ -15,4 +15,4 @@ python3 tools/pmc_summary.py gpurun_out/pmc_stress_fetch > gpurun_out/stress_pmc
 python3 tools/pmc_summary.py gpurun_out/pmc_stress_write > gpurun_out/stress_pmc_write_size.txt
 python3 tools/pmc_summary.py gpurun_out/pmc_stress_sq > gpurun_out/stress_pmc_sq.txt
 cp gpurun_out/pmc_stress_sq/bench.json gpurun_out/stress_bench_under_pmc.json
-grep -h -A12 "wf_extend_kernel<false>" gpurun_out/stress_pmc_fetch_size.txt gpurun_out/stress_pmc_write_size.txt gpurun_out/stress_pmc_sq.txt | cut -c1-100
+grep -h -A12 "wf_extend_kernel<false, true>" gpurun_out/stress_pmc_fetch_size.txt gpurun_out/stress_pmc_write_size.txt gpurun_out/stress_pmc_sq.txt | cut -c1-100
