@@ -316,9 +316,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
 // claims `chunk` consecutive pool entries at a time (one returning atomic per chunk, on the queue word of its XCD's
 // region of the pool) and every lane that finishes a ray stores its hit and takes the next entry of its wave's
 // chunk (64-bit ballot of the idle lanes, lane prefix count).  Lanes only run dry once, when the pool is drained.
-// Which visit the wave runs next: `vote_leaf_weight` == 0 -> at most `node_burst` node trips, then one leaf trip;
-// k > 0 -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a refill once `refill_min`
-// lanes are idle.  One ray's visits keep their order either way; only which lanes run together changes.
+// Which visit the wave runs next: VOTE false (`vote_leaf_weight` == 0) -> at most `node_burst` node trips, then one
+// leaf trip; VOTE true (weight k > 0) -> whatever most lanes wait for, a leaf visit weighing k/16 node visits, and a
+// refill once `refill_min` lanes are idle.  One ray's visits keep their order either way; only which lanes run
+// together changes.
 template <bool COUNT, bool VOTE>
 __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
