@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTCORE_ABI_VERSION 1
+#define RTCORE_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -196,10 +196,28 @@ int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera
  * d_output (device, float[3*n_pixel], row-major, y up).  `semantic_batch` is
  * upstream's <batch_size>: samples k*B .. k*B+B-1 share one jittered primary
  * ray and are summed before being added to the buffer.  first_sample must be a
- * multiple of semantic_batch.  Asynchronous on `stream` (a hipStream_t, may be null). */
+ * multiple of semantic_batch.  `stream` is a hipStream_t (may be null).  In megakernel mode the call only queues work on
+ * `stream`.  In wavefront mode (the default) the host drives the stage kernels and WAITS inside the call, a few
+ * iterations behind the device, until every pass but the tail of the last has drained; the result is complete once
+ * `stream` is synchronised.  A context's working memory (sample slots, path pools, control block, counters) is reused by
+ * every call: drive a context from one stream at a time, and synchronise that stream before using another. */
 int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch,
                 int max_depth, const float ambient[3], float russian_roulette,
                 float* d_output, void* stream);
+
+/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same result bit for bit as rt_raytrace,
+ * but the call allocates, creates and frees nothing: the sample slots between the path kernel and the ordered sum
+ * live in a static device array of RT_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process
+ * ends, every pass is one launch of the megakernel design whatever RT_OPT_MODE says, and no timing events are recorded.
+ * The frame must fit twice: 2 * n_pixel * 12 bytes <= RT_STATIC_SCRATCH_BYTES (2 796 202 pixels), else RT_ERR_CAPACITY;
+ * samples per pass = what fits (27 at 2000x1200).  All contexts of a device share that device's array and a call
+ * leaves its slots behind: every slot and the carry plane are written before they are read, so nothing needs clearing,
+ * but two calls that overlap in time on one GPU (two streams, two threads, two contexts) race.  Asynchronous on `stream`. */
+#define RT_STATIC_SCRATCH_BYTES (64u << 20)
+int rt_raytrace_static(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch,
+                       int max_depth, const float ambient[3], float russian_roulette,
+                       float* d_output, void* stream);
 
 /* Replaces vrt::post_process (include/raytrace.cuh:17, cuda/raytrace.cu:249-297):
  * c /= spp, clamp to [0,1], c = pow(c, 1/gamma), in place.  Asynchronous on `stream`

@@ -42,6 +42,7 @@ OPT_WF_REFILL = 14
 OPT_WF_BLOCK = 15
 OPT_WF_LANES = 16
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
+STATIC_SCRATCH_BYTES = 64 << 20
 
 
 class RtObject(C.Structure):
@@ -58,7 +59,7 @@ class RtTransform(C.Structure):
 
 EXPORTS = [
     "rt_last_error", "rt_abi_version", "rt_build_bvh", "rt_apply_transform", "rt_create", "rt_destroy", "rt_set_option",
-    "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_post_process", "rt_primary_rays",
+    "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_raytrace_static", "rt_post_process", "rt_primary_rays",
     "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_device_alloc", "rt_device_free",
     "rt_device_zero", "rt_copy_to_host", "rt_copy_to_device", "rt_synchronize",
 ]
@@ -97,6 +98,7 @@ def load():
         "rt_init_randstate": [vp, u64, i32, i32],
         "rt_setup_raytrace": [vp, i32, i32, fp, fp, fp, f32],
         "rt_raytrace": [vp, i32, i32, i32, i32, i32, fp, f32, vp, vp],
+        "rt_raytrace_static": [vp, i32, i32, i32, i32, i32, fp, f32, vp, vp],
         "rt_post_process": [vp, i32, i32, f32, vp, vp],
         "rt_primary_rays": [vp, u32, vp, vp],
         "rt_closest_hit": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -202,6 +204,10 @@ class Context:
 
     def raytrace(self, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, rr, d_out, stream=0):
         check(self.lib.rt_raytrace(self.h, n_pixel, first_sample, spp, semantic_batch, max_depth, f3(ambient), rr, d_out, stream))
+
+    def raytrace_static(self, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, rr, d_out, stream=0):
+        """rt_raytrace without any allocation: sample slots in the library's static device array."""
+        check(self.lib.rt_raytrace_static(self.h, n_pixel, first_sample, spp, semantic_batch, max_depth, f3(ambient), rr, d_out, stream))
 
     def post_process(self, n_pixels, spp, gamma, d_out, stream=0):
         check(self.lib.rt_post_process(self.h, n_pixels, spp, gamma, d_out, stream))

@@ -666,6 +666,13 @@ __global__ __launch_bounds__(RT_BLOCK) void post_process_kernel(int n_pixels, in
 // ---------------------------------------------------------------------------
 // context and C ABI
 // ---------------------------------------------------------------------------
+// Sample slots of rt_raytrace_static: one array per GPU the library runs on, held until the process ends.  In host
+// code the array's name is only a handle for hipGetSymbolAddress; the device address each GPU gives its copy is looked
+// up once per device in rt_create and kept in g_static_slots[device], which is what kernels and copies are given.
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+#define RT_MAX_DEVICES 64
+static float* g_static_slots[RT_MAX_DEVICES];
+
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
@@ -803,6 +810,17 @@ int rt_create(int device_id, rt_context** out) {
     hipError_t e = hipMalloc((void**)&c->d_counters, RT_CNT_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) { delete c; return fail(RT_ERR_DEVICE, std::string("hipMalloc counters: ") + hipGetErrorString(e)); }
     (void)hipMemset(c->d_counters, 0, RT_CNT_WORDS * sizeof(unsigned long long));
+    if (device_id < RT_MAX_DEVICES && !g_static_slots[device_id]) {
+        // this device's copy of the static slot array (the device is current: hipSetDevice above)
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hipFree(c->d_counters);
+            delete c;
+            return fail(RT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        }
+        g_static_slots[device_id] = (float*)p;
+    }
     *out = c;
     return RT_OK;
 }
@@ -1122,33 +1140,52 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     return RT_OK;
 }
 
-int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
-                float russian_roulette, float* d_output, void* stream) {
-    if (!ctx || !ambient || !d_output) return fail(RT_ERR_INVALID, "rt_raytrace: null argument");
-    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_raytrace: no scene uploaded");
-    if (!ctx->have_camera) return fail(RT_ERR_NO_CAMERA, "rt_raytrace: rt_setup_raytrace not called");
-    if (n_pixel != ctx->cam.width * ctx->cam.height) return fail(RT_ERR_INVALID, "rt_raytrace: n_pixel does not match the camera frame");
-    if (spp < 0 || first_sample < 0 || semantic_batch <= 0 || max_depth < 0) return fail(RT_ERR_INVALID, "rt_raytrace: negative count");
-    if (first_sample % semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: first_sample must be a multiple of semantic_batch");
-    if ((long long)first_sample + spp > 0x7FFFFFFFLL - semantic_batch) return fail(RT_ERR_INVALID, "rt_raytrace: sample index overflow");
+// Body of rt_raytrace and rt_raytrace_static.  `fixed_slots` == nullptr: the slot buffer belongs to the context and grows
+// on demand, the context's kernel design is used.  Otherwise the slots are `fixed_bytes` of memory the caller of this
+// function provides, nothing is allocated, created or freed, and every pass is one path_kernel launch.
+static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth,
+                         const float ambient[3], float russian_roulette, float* d_output, hipStream_t s, float* fixed_slots,
+                         size_t fixed_bytes) {
+    const std::string name(who);
+    if (!ctx || !ambient || !d_output) return fail(RT_ERR_INVALID, name + ": null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, name + ": no scene uploaded");
+    if (!ctx->have_camera) return fail(RT_ERR_NO_CAMERA, name + ": rt_setup_raytrace not called");
+    if (n_pixel != ctx->cam.width * ctx->cam.height) return fail(RT_ERR_INVALID, name + ": n_pixel does not match the camera frame");
+    if (spp < 0 || first_sample < 0 || semantic_batch <= 0 || max_depth < 0) return fail(RT_ERR_INVALID, name + ": negative count");
+    if (first_sample % semantic_batch) return fail(RT_ERR_INVALID, name + ": first_sample must be a multiple of semantic_batch");
+    if ((long long)first_sample + spp > 0x7FFFFFFFLL - semantic_batch) return fail(RT_ERR_INVALID, name + ": sample index overflow");
     if (spp == 0) return RT_OK;
-    if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, "rt_raytrace: more than 2^30-1 pixels");
-    if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, "rt_raytrace: BVH deeper than the traversal stack allows");
+    if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, name + ": more than 2^30-1 pixels");
+    if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, name + ": BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = (hipStream_t)stream;
-    // slot buffer: one float3 per (sample of the pass, pixel); grown on demand, kept by the context
-    // Long passes pay the pipeline's drain (a dozen launches with a thinning pool) less often; the buffer is sized for
-    // a 288 GB device but kept below RT_SLOTS_MAX_BYTES.
+    // slot buffer: one float3 per (sample of the pass, pixel), then one carry plane
+    // Long passes pay the pipeline's drain (a dozen launches with a thinning pool) less often; the context's buffer is sized
+    // for a 288 GB device but kept below RT_SLOTS_MAX_BYTES.
     const size_t plane = (size_t)n_pixel * 3 * sizeof(float);
     int pass = spp < ctx->opt_pass ? spp : ctx->opt_pass;
-    const size_t fit = RT_SLOTS_MAX_BYTES / plane;
+    const size_t fit = (fixed_slots ? fixed_bytes : RT_SLOTS_MAX_BYTES) / plane;
+    if (fixed_slots && fit < 2)
+        return fail(RT_ERR_CAPACITY, name + ": a frame of " + std::to_string(n_pixel) + " pixels needs " + std::to_string(2 * plane) +
+                                     " bytes of sample slots, the static array holds " + std::to_string(fixed_bytes));
     if (fit >= 2 && (size_t)pass > fit - 1) pass = (int)(fit - 1);
-    const size_t need = ((size_t)pass + 1) * plane;
-    if (need > ctx->slots_bytes) {
-        HIP_TRY(hipStreamSynchronize(s));
-        if (ctx->d_slots) { HIP_TRY(hipFree(ctx->d_slots)); ctx->d_slots = nullptr; ctx->slots_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&ctx->d_slots, need));
-        ctx->slots_bytes = need;
+    float* slots = fixed_slots;
+    if (!fixed_slots) {
+        size_t need = ((size_t)pass + 1) * plane;
+        if (need > ctx->slots_bytes) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (ctx->d_slots) { HIP_TRY(hipFree(ctx->d_slots)); ctx->d_slots = nullptr; ctx->slots_bytes = 0; }
+            // a device with less free memory than the defaults assume gets shorter passes, not an error
+            hipError_t e = hipMalloc((void**)&ctx->d_slots, need);
+            while (e == hipErrorOutOfMemory && pass > 1) {
+                (void)hipGetLastError();
+                pass = (pass + 1) / 2;
+                need = ((size_t)pass + 1) * plane;
+                e = hipMalloc((void**)&ctx->d_slots, need);
+            }
+            if (e != hipSuccess) { ctx->d_slots = nullptr; return fail(RT_ERR_DEVICE, name + ": hipMalloc of the sample slots: " + hipGetErrorString(e)); }
+            ctx->slots_bytes = need;
+        }
+        slots = ctx->d_slots;
     }
     PathParams pp;
     pp.cam = ctx->cam;
@@ -1158,7 +1195,7 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     pp.ambient[0] = ambient[0]; pp.ambient[1] = ambient[1]; pp.ambient[2] = ambient[2];
     pp.rr = russian_roulette;
     pp.key0 = (uint32_t)ctx->seed; pp.key1 = (uint32_t)(ctx->seed >> 32);
-    pp.slots = ctx->d_slots;
+    pp.slots = slots;
     pp.counters = ctx->d_counters;
     pp.tiles_x = (ctx->cam.width + 15) / 16;
     pp.tiles_y = (ctx->cam.height + 15) / 16;
@@ -1166,28 +1203,44 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
     pp.chunk = ctx->opt_chunk;
     pp.lds_slots = lds_slots(ctx);
     pp.sort_rays = ctx->opt_wf_sort;
+    const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
     for (int done = 0; done < spp; done += pass) {
         pp.first_sample = first_sample + done;
         pp.n_samples = spp - done < pass ? spp - done : pass;
         pp.n_chunks = (pp.n_samples + pp.chunk - 1) / pp.chunk;
         const long long nblocks = (long long)pp.tiles_x * pp.tiles_y * pp.n_chunks;
-        if (nblocks > 0x7FFFFFFFLL) return fail(RT_ERR_INVALID, "rt_raytrace: grid too large");
-        if (ctx->opt_mode == 1) {
+        if (nblocks > 0x7FFFFFFFLL) return fail(RT_ERR_INVALID, name + ": grid too large");
+        if (wavefront) {
             const int rc = wavefront_pass(ctx, pp, s);
             if (rc) return rc;
         } else {
-            const int tk = timing_begin(ctx, 2, s);
+            const int tk = fixed_slots ? -1 : timing_begin(ctx, 2, s);     // timing creates events on demand
             if (ctx->opt_counters) hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
             else hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
             timing_end(ctx, tk, s);
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixel + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, n_pixel, pp.first_sample,
-                           pp.n_samples, semantic_batch, done + pass >= spp ? 1 : 0, (const float*)ctx->d_slots,
-                           ctx->d_slots + (size_t)pass * (size_t)n_pixel * 3, d_output);
+                           pp.n_samples, semantic_batch, done + pass >= spp ? 1 : 0, (const float*)slots,
+                           slots + (size_t)pass * (size_t)n_pixel * 3, d_output);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
+}
+
+int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
+                float russian_roulette, float* d_output, void* stream) {
+    return raytrace_body("rt_raytrace", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, russian_roulette, d_output,
+                         (hipStream_t)stream, nullptr, 0);
+}
+
+int rt_raytrace_static(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
+                       float russian_roulette, float* d_output, void* stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_raytrace_static: null argument");
+    float* slots = ctx->device < RT_MAX_DEVICES ? g_static_slots[ctx->device] : nullptr;
+    if (!slots) return fail(RT_ERR_DEVICE, "rt_raytrace_static: no static slot array on this device");
+    return raytrace_body("rt_raytrace_static", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, russian_roulette, d_output,
+                         (hipStream_t)stream, slots, (size_t)RT_STATIC_SCRATCH_BYTES);
 }
 
 int rt_post_process(rt_context* ctx, int n_pixels, int spp, float gamma, float* d_output, void* stream) {

@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in rtcore.h but not exported"
     assert sorted(capi.EXPORTS) == declared
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_binding_constants_match_the_header():
