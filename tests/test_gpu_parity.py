@@ -422,3 +422,51 @@ def test_full_size_sample_split_sums_to_the_whole_frame(gpu_ctx):
         gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
     assert same_f32(whole, part)
     assert cnt[capi.CNT_PATHS] == 2000 * 1200 * 32 and np.isfinite(whole).all() and whole.mean() > 0
+
+
+def test_stress_scene_at_its_real_size(gpu_ctx):
+    """The 30 M-triangle scene as benchmarked (8x8 instances of 470k triangles, 66 objects, 4.4 GB packed, deepest stacks,
+    packed indices near 2^25) at the full 3840x2160 frame: every primary ray and 250k incoherent secondary rays are traced
+    on the GPU; the oracle checks a strided sample of 60k primaries and 40k secondaries bit for bit (object, triangle,
+    t, u, v).  Then a whole reduced frame (480x270, 4 spp) with the default wavefront options against the oracle's render."""
+    asm = scene.stress(width=3840, height=2160, n_samples=4)
+    p = Pair(gpu_ctx, asm)
+    stats = gpu_ctx.scene_stats()
+    assert stats["triangles"] > 30_000_000 and stats["objects"] == 66
+    rays = p.gpu_primary_rays(0)
+    assert len(rays) == 3840 * 2160
+    go, gt, gtt, gu, gv = p.gpu_hits(rays)
+    sel = np.arange(0, len(rays), 137)[:60_000]
+    o, t, tt, u, v, _ = p.oracle.closest_hit(rays[sel])
+    assert np.array_equal(go[sel], o), f"{(go[sel] != o).sum()} object mismatches"
+    assert np.array_equal(gt[sel], t), f"{(gt[sel] != t).sum()} triangle mismatches"
+    assert same_f32(gtt[sel], tt) and same_f32(gu[sel], u) and same_f32(gv[sel], v)
+    assert (go >= 0).mean() > 0.5 and len(np.unique(go[sel])) > 30          # most of the instances are seen
+    # bounce-like rays: origins on the surfaces the camera sees, directions uniform on the sphere
+    rng = np.random.RandomState(23)
+    pick = rng.choice(np.nonzero(go >= 0)[0], size=250_000, replace=False)
+    origin = rays[pick, :3] + rays[pick, 3:] * gtt[pick, None]
+    d = rng.standard_normal((len(pick), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = np.concatenate([origin, d], axis=1).astype(np.float32)
+    so, st, stt, su, sv = p.gpu_hits(sec)
+    sel = np.arange(0, len(sec), 6)[:40_000]
+    o, t, tt, u, v, _ = p.oracle.closest_hit(sec[sel])
+    assert np.array_equal(so[sel], o) and np.array_equal(st[sel], t)
+    assert same_f32(stt[sel], tt) and same_f32(su[sel], u) and same_f32(sv[sel], v)
+    # the whole path loop on this geometry, reduced frame
+    cfg = p.cfg
+    cfg.width, cfg.height = 480, 270
+    gpu_ctx.init_randstate(SEED, cfg.width, cfg.height)
+    gpu_ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+    ref, rcnt = p.oracle.render(orc.make_params(cfg, SEED, 4), 0, 4)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 27)
+    try:
+        got, gcnt = p.gpu_render(0, 4, 4)
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2] and gcnt[capi.CNT_SHADED] == rcnt[3]
+    assert gcnt[capi.CNT_MAX_STACK] > 11                                      # the private spill levels were in use
