@@ -11,16 +11,23 @@ one process per GPU) the scene is replicated, every rank traces its own sample r
 inside the timed region.  Rank 0 prints ONE JSON line.
 
 value      = whole-job Mrays/s: closest-hit queries (device counter) of all ranks / max-over-ranks time.
-roofline   = the dominant kernel (wavefront: wf_extend_kernel, the closest-hit walk; megakernel: path_kernel):
-             algorithmic bytes per launch / mean launch time, against 8 TB/s HBM.  Launch times come from HIP
-             events the library records on the launch stream around every launch of that kernel in the timed
-             region (rt_get_timing).  Bytes per ray = 32*box_tests + 36*triangle_tests for the walk (+ 100*shaded
-             + 16*texture_fetches when the kernel also shades), per-ray counts measured by an instrumented pass
-             of the same kernels on the same workload.
+roofline   = the dominant kernel (wavefront: wf_extend_kernel, the closest-hit walk; megakernel: path_kernel) against
+             8 TB/s of HBM.  `achieved` = algorithmic bytes per launch / mean launch time, where the algorithmic bytes
+             are what the launch MUST move through HBM: every ray's pool record in (16 bytes for a new camera ray, 32 for
+             a continued path) and its hit record out (16 bytes), plus the walked part of the scene (node and triangle
+             records) once.  Launch times come from HIP events the library records on the launch stream around every
+             launch of that kernel in the timed region (rt_get_timing).  `traffic` = HBM bytes per launch from the
+             FETCH_SIZE (x2 on gfx950) and WRITE_SIZE counter passes of this same command, taken from
+             profiles/<round>/traffic.json -- only when that file was made from the kernel sources being run (source
+             hash), else null.  `demand_bytes_per_ray` = 32*box_tests + 36*triangle_tests: what the walk asks of the
+             memory hierarchy per ray; LDS, L1, L2 and Infinity Cache serve nearly all of it, so it is not an HBM figure
+             (it would be 15 TB/s).  `binding` names the roof the counters say the kernel sits under.
 cpu_baseline = the CPU oracle (a port of upstream's logic, OpenMP) on a bounded sample of the same
-             workload, rank 0, N = 1 only.
+             workload, rank 0, N = 1 only; `cfg1` inside it = the luyu scene at 400x240, 16 spp, depth 8 in full.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -36,8 +43,38 @@ FRAME_SPP = 8192
 HBM_PEAK_GBPS = 8000.0
 
 
+HASHED_SOURCES = ("raytrace_amd/csrc/rt_kernels.hip", "raytrace_amd/csrc/rt_device.h", "raytrace_amd/csrc/rt_packed.h",
+                  "raytrace_amd/csrc/rt_host.cpp", "raytrace_amd/csrc/rt_host.h", "Makefile")
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def source_hash():
+    """Identifies the kernels and the scene packing a counter pass was taken on."""
+    h = hashlib.sha256()
+    for f in HASHED_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def workload_key(args, cfg):
+    return f"{args.scene}_{cfg.width}x{cfg.height}_detail{args.detail:g}_depth{cfg.max_depth}"
+
+
+def counter_passes(key):
+    """The committed rocprofv3 --pmc summary for this workload, if one was taken on the sources being run."""
+    sh = source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        if doc.get("source_hash") == sh and key in doc.get("workloads", {}):
+            return doc["workloads"][key], os.path.relpath(path, ROOT)
+    return None, f"none: no profiles/r*/traffic.json was taken on these kernel sources (hash {sh}) for {key}"
 
 
 def main():
@@ -160,6 +197,7 @@ def main():
 
     accum = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
     staging = torch.zeros_like(accum) if world > 1 else None
+    reduced = None
     stream = torch.cuda.current_stream().cuda_stream
     spp = args.spp_per_step
     assert spp % args.batch == 0, "--spp-per-step must be a multiple of --batch"
@@ -169,6 +207,7 @@ def main():
         return (step * world + rank) * spp
 
     def run_step(step, ev=None):
+        nonlocal reduced
         if ev:
             ev[0].record()
         ctx.raytrace(npix, first_sample(step), spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette,
@@ -179,8 +218,11 @@ def main():
             if backend == "nccl":
                 staging.copy_(accum)
                 reduce_to_root(staging, 0)
+                reduced = staging
             else:
-                reduce_to_root(accum.cpu(), 0)
+                host = accum.cpu()
+                reduce_to_root(host, 0)
+                reduced = host.cuda()
 
     # ---- instrumented pass: per-ray work mix of this kernel on this workload (not timed) ----
     ctx.set_option(capi.OPT_COUNTERS, 1)
@@ -265,29 +307,37 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         mrays = rays / elapsed / 1e6
         my_rays = float(cnt[capi.CNT_RAYS])
+        my_paths = float(cnt[capi.CNT_PATHS])
+        demand_bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"]
+        walked_scene_bytes = 128.0 * stats["inner_nodes"] + 48.0 * stats["triangles"]
         if tim["extend_launches"]:
             kname, k_ms_total, k_launches = "wf_extend_kernel", tim["extend_ms"], tim["extend_launches"]
-            k_bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"]
+            # per ray: the pool record in (one 16-byte piece for a new camera ray, two for a continued path) and the hit out
+            algo_bytes_per_ray = 16.0 + 16.0 * (1.0 - my_paths / max(1.0, my_rays)) + 16.0
+            algo_scene_bytes = walked_scene_bytes
         else:
             kname, k_ms_total, k_launches = "path_kernel", tim["path_ms"], tim["path_launches"]
-            k_bytes_per_ray = bytes_per_ray
+            # rays never leave the registers; per path one 12-byte sample slot out; the shading records are walked as well
+            algo_bytes_per_ray = 12.0 * my_paths / max(1.0, my_rays)
+            algo_scene_bytes = float(stats["device_bytes"])
         k_ms = k_ms_total / max(1, k_launches)
-        algo_bytes_per_launch = my_rays * k_bytes_per_ray / max(1, k_launches)
+        rays_per_launch = my_rays / max(1, k_launches)
+        algo_bytes_per_launch = rays_per_launch * algo_bytes_per_ray + algo_scene_bytes
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, prof = None, {}
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        # the committed counter passes were taken on the default workload; they say nothing about another scene or frame size
-        default_workload = args.scene == "formula1" and (args.width, args.height) == (2000, 1200) and args.detail == 1.0 and not args.depth
-        if os.path.exists(tpath) and default_workload:
-            try:
-                prof = json.load(open(tpath)).get(kname, {})
-                traffic = prof.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # every 16-byte piece a lane loads from memory is one access of the CU's vector L1, which serves about one per
-        # clock; node records the workgroup holds in LDS do not go through it.  Per ray: 7 pieces per node record from
-        # memory, 3 per triangle record, 2 for the ray itself and 1 for the hit record written back
-        l1_accesses_per_ray = (7.0 * mix["node_visits_per_ray"] * (1.0 - mix["node_visits_from_lds"]) + 3.0 * mix["tri_tests_per_ray"] + 3.0)
+        pmc, pmc_source = counter_passes(workload_key(args, cfg))
+        kp = (pmc or {}).get(kname, {})
+        traffic = kp.get("hbm_bytes_per_launch")
+        # the counter passes ran the same command; their launch time (profiled clocks run ~3 % lower) prices their bytes
+        traffic_gbps = traffic / (kp["kernel_ms_mean"] * 1e-3) / 1e9 if traffic and kp.get("kernel_ms_mean") else None
+        binding = None
+        if kp.get("valu_issue_frac") is not None:
+            roofs = {"vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles)": kp.get("valu_issue_frac"),
+                     "vector L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES / CUs / cycles; ceiling 1)": kp.get("l1_accesses_per_clk_per_cu"),
+                     "HBM traffic / 8 TB/s (FETCH_SIZE x 2 + WRITE_SIZE)": round(traffic_gbps / HBM_PEAK_GBPS, 4) if traffic_gbps else None}
+            roofs = {k: v for k, v in roofs.items() if v is not None}
+            top = max(roofs, key=roofs.get)
+            binding = {"roof": top, "frac": roofs[top], "all": roofs, "wave_cycle_split": kp.get("wave_cycle_split"),
+                       "resident_waves_mean": kp.get("mean_waves_in_flight"), "resident_wave_limit": kp.get("resident_wave_limit")}
         out = {
             "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
                       else f"Mrays/s (closest-hit queries), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
@@ -305,28 +355,49 @@ def main():
             "work_mix": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mix.items()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "traffic_GBps": round(traffic_gbps, 1) if traffic_gbps else None,
+                         "traffic_frac": round(traffic_gbps / HBM_PEAK_GBPS, 4) if traffic_gbps else None,
                          "kernel": kname, "kernel_ms_mean": round(k_ms, 4), "launches": int(k_launches),
-                         "bytes_per_ray": round(k_bytes_per_ray, 1), "rays_per_launch": round(my_rays / max(1, k_launches), 1),
-                         # from the committed PMC passes of this same command (profiles/r01_traffic.json)
-                         "valu_utilisation": prof.get("valu_utilisation"), "mean_waves_in_flight": prof.get("mean_waves_in_flight"),
-                         "resident_wave_limit": prof.get("resident_wave_limit")},
+                         "algorithmic_bytes_per_ray": round(algo_bytes_per_ray, 2), "algorithmic_scene_bytes_per_launch": int(algo_scene_bytes),
+                         "algorithmic_bytes_per_launch": int(algo_bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
+                         "demand_bytes_per_ray": round(demand_bytes_per_ray, 1),
+                         "demand_note": "32*box_tests + 36*triangle_tests per ray: requested of LDS/L1/L2/Infinity Cache, not of HBM",
+                         "counter_passes": pmc_source},
+            "binding": binding,
             "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "shade_ms": round(tim["shade_ms"], 2),
                              "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},
-            "l1_access_bound": {"accesses_per_ray": round(l1_accesses_per_ray, 1),
-                                "achieved_G_per_s": round(my_rays * l1_accesses_per_ray / max(1e-9, k_ms_total * 1e-3) / 1e9, 1),
-                                "peak_G_per_s": 256 * 2.4, "frac": round(my_rays * l1_accesses_per_ray / max(1e-9, k_ms_total * 1e-3) / 1e9 / (256 * 2.4), 4),
-                                "note": "one 16-byte lane access per clock per CU (tools/microbench/gather.hip); LDS-served node visits excluded"},
+            "source_hash": source_hash(), "workload_key": workload_key(args, cfg),
             "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(asm, objs, args)
+            out["cpu_baseline"]["cfg1"] = cpu_cfg1(args)
         if args.save_image:
-            save_image(ctx, accum, cfg, (args.warmup + args.steps) * spp * world, args.save_image)
+            # with several ranks the picture is the reduced buffer of the last step, which holds every rank's samples so far
+            save_image(ctx, reduced if world > 1 else accum, cfg, (args.warmup + args.steps) * spp * world, args.save_image)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_cfg1(args):
+    """BASELINE config 1 in full on the CPU path: the luyu scene (assets/scene/scene_luyu.txt:6-58, stand-in statue) at
+    400x240, 16 spp, depth 8."""
+    from oracle import oracle as orc
+    from raytrace_amd import scene
+    asm = scene.luyu(400, 240, 16)
+    t0 = time.perf_counter()
+    objs = scene.finalize(asm, backend=orc.OracleBackend())
+    t_build = time.perf_counter() - t0
+    sc = orc.Scene(objs, asm.materials, asm.textures)
+    t0 = time.perf_counter()
+    _, cnt = sc.render(orc.make_params(asm.config, SEED, args.batch), 0, 16)
+    dt = time.perf_counter() - t0
+    return {"workload": f"scene_luyu 400x240, 16 spp, depth 8, {asm.n_triangles} triangles, whole frame", "seconds_per_frame": round(dt, 3),
+            "value": round(float(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": orc.num_threads(), "kind": "port",
+            "transform_and_bvh_build_s": round(t_build, 3)}
 
 
 def cpu_baseline(asm, objs, args):

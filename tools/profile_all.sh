@@ -1,17 +1,26 @@
 #!/bin/bash
-# Everything the committed profile summaries come from, in one GPU job: the default bench, a kernel trace, and three
-# counter passes (each in a run of its own).  Results under gpurun_out/; copy the summaries to profiles/<round>/.
+# Everything the committed profile summaries come from, in one GPU job: the default bench, a kernel trace, and the counter
+# passes (each counter set in a run of its own, no trace domains).  Usage: tools/profile_all.sh <tag> [bench args]
+# Results under gpurun_out/<tag>/; tools/make_traffic.py <tag> <round> turns them into profiles/<round>/.
 set -e
-mkdir -p gpurun_out
-timeout -k 10 300 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.log
-tools/prof_trace.sh final
-tools/prof_pmc.sh fetch FETCH_SIZE
-tools/prof_pmc.sh write WRITE_SIZE
-tools/prof_pmc.sh sq "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
-python3 tools/pmc_summary.py gpurun_out/pmc_fetch > gpurun_out/pmc_fetch_size.txt
-python3 tools/pmc_summary.py gpurun_out/pmc_write > gpurun_out/pmc_write_size.txt
-python3 tools/pmc_summary.py gpurun_out/pmc_sq > gpurun_out/pmc_sq_valu.txt
-cp "$(find gpurun_out/prof_final -name '*kernel_stats.csv' | head -1)" gpurun_out/bench_kernel_stats.csv
-cp gpurun_out/prof_final/bench.json gpurun_out/bench_under_rocprof.json
-cut -c1-160 gpurun_out/bench_default.json
-head -4 gpurun_out/bench_kernel_stats.csv | cut -c1-160
+tag=$1; shift
+export TMPDIR=/tmp
+out=gpurun_out/$tag
+mkdir -p $out
+timeout -k 10 400 python3 bench.py "$@" > $out/bench_default.json 2> $out/bench_default.log
+mkdir -p $out/trace
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/bench_under_rocprof.json 2> $out/trace/bench.err
+cp "$(find $out/trace -name '*kernel_stats.csv' | head -1)" $out/bench_kernel_stats.csv
+pmc() {   # <name> <counters>
+    mkdir -p $out/pmc_$1
+    timeout -s KILL 500 rocprofv3 --pmc $2 --output-format csv -d $out/pmc_$1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "${@:3}" > $out/pmc_$1/bench.json 2> $out/pmc_$1/bench.err
+    python3 tools/pmc_summary.py $out/pmc_$1 > $out/pmc_$1.txt
+}
+pmc fetch "FETCH_SIZE" "$@"
+pmc write "WRITE_SIZE" "$@"
+pmc sq "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "$@"
+pmc stall "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_INSTS_LDS" "$@"
+pmc stall2 "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "$@"
+rm -rf $out/trace/*/  # the raw per-process trace directories are large; the stats file was copied out
+cut -c1-200 $out/bench_default.json
+head -4 $out/bench_kernel_stats.csv | cut -c1-160
