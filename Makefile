@@ -48,11 +48,14 @@ bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_mod
 $(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
+$(CSRC)/rt_multi.o: $(CSRC)/rt_multi.hip include/rtcore.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HOSTFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/rt_kernels.o $(CSRC)/rt_host.o
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+$(LIB): $(CSRC)/rt_kernels.o $(CSRC)/rt_host.o $(CSRC)/rt_multi.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -110,7 +110,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytrace_amd import capi, scene
-    from raytrace_amd.dist import reduce_to_root
+    from raytrace_amd.dist import make_group, reduce_to_root
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -195,6 +195,23 @@ def main():
             f"{stats['device_bytes'] / 1e6:.1f} MB packed, models generated in {t_assemble:.1f}s, "
             f"transform + BVH build {t_build:.1f}s ({os.environ.get('RT_HOST_THREADS', 'up to 16')} threads), re-pack + upload {t_upload:.1f}s")
 
+    # the reduce goes through the library (rt_group_create / rt_reduce_to_root); the gloo rehearsal, whose ranks share a
+    # device (RCCL takes a device once per communicator), sums through host memory instead
+    group, reduce_via = None, "none (single GPU)"
+    if world > 1 and backend == "nccl":
+        try:
+            group = make_group(ctx, rank, world)
+        except Exception as e:                      # reported on the bench line; the ranks then agree on torch's reduce below
+            log(f"rank {rank}: rt_group_create failed: {e}")
+        ok = torch.tensor([1 if group is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if group is not None:
+                group.close()
+            group = None
+        reduce_via = "rt_reduce_to_root (one ncclReduce through the C ABI)" if group is not None else "torch.distributed.reduce (rt_group_create failed on some rank)"
+    elif world > 1:
+        reduce_via = f"torch.distributed.reduce over {backend} through host memory (rehearsal)"
     accum = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
     staging = torch.zeros_like(accum) if world > 1 else None
     reduced = None
@@ -215,13 +232,18 @@ def main():
         if ev:
             ev[1].record()
         if world > 1:
-            if backend == "nccl":
+            if group is not None:
+                # the library's own collective: one ncclReduce (RCCL) of a copy of the buffer onto rank 0, on the render stream
                 staging.copy_(accum)
-                reduce_to_root(staging, 0)
+                reduce_to_root(group, staging, stream)
+                reduced = staging
+            elif backend == "nccl":
+                staging.copy_(accum)
+                dist.reduce(staging, dst=0, op=dist.ReduceOp.SUM)
                 reduced = staging
             else:
                 host = accum.cpu()
-                reduce_to_root(host, 0)
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
                 reduced = host.cuda()
 
     # ---- instrumented pass: per-ray work mix of this kernel on this workload (not timed) ----
@@ -348,7 +370,8 @@ def main():
                                    f"{frame_spp}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
                        "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
                        "mode": args.mode or "library default (wavefront)",
-                       "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU"},
+                       "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU",
+                       "reduce": reduce_via},
             "seconds_per_frame": round(ms_per_step * 1e-3 * frame_spp / (spp * world), 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "gpu_ms_per_step_events": round(float(np.mean(step_ms)), 3) if step_ms else None,
@@ -376,6 +399,8 @@ def main():
             # with several ranks the picture is the reduced buffer of the last step, which holds every rank's samples so far
             save_image(ctx, reduced if world > 1 else accum, cfg, (args.warmup + args.steps) * spp * world, args.save_image)
         print(json.dumps(out), flush=True)
+    if group is not None:
+        group.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -248,6 +248,34 @@ int rt_get_timing(rt_context* ctx, double out[8]);
  * [3]=device bytes of the packed scene, [4]=objects. */
 int rt_scene_stats(rt_context* ctx, uint64_t out[8]);
 
+/* ---- multi-GPU: sample split and the sum onto the root GPU ----
+ * No upstream counterpart (upstream is single-GPU, no collective anywhere).  The frame splits where upstream's batch
+ * loop runs (csrc/worker.cpp:71-91): batches are independent, so each GPU traces a contiguous run of whole batches of
+ * every pixel (scene replicated), and the float buffers are added onto the root before rt_post_process with the total
+ * spp.  The random streams are keyed by (pixel, global sample), so the set of samples is the same for any GPU count;
+ * only the order of the float additions across GPUs differs. */
+
+int rt_get_device(rt_context* ctx, int* device);
+
+/* Part `part` of `parts`: global samples [*first_sample, *first_sample + *count), whole batches except where the frame ends. */
+int rt_partition_samples(int n_samples, int semantic_batch, int parts, int part, int* first_sample, int* count);
+
+typedef struct rt_group rt_group;
+#define RT_GROUP_ID_BYTES 128
+/* ncclGetUniqueId: call in one process, hand the bytes to the others (any channel), pass to rt_group_create. */
+int rt_group_unique_id(uint8_t id[RT_GROUP_ID_BYTES]);
+/* The contexts this process drives (n_local >= 1; one host thread per GPU, or one process per GPU with n_local = 1).
+ * Their distinct devices take RCCL ranks first_rank, first_rank + 1, ... of a communicator of `world` ranks; contexts
+ * that share a device share its rank.  id = null: the world is this process alone (ncclCommInitAll). */
+int rt_group_create(rt_context* const* ctxs, int n_local, int first_rank, int world, const uint8_t* id, rt_group** out);
+int rt_group_destroy(rt_group* group);
+/* Adds up d_buffers[k] (device, `count` floats, k-th context of rt_group_create, its work queued on streams[k]; streams
+ * may be null = null streams) over the whole world: contexts that share a device are added on the device in the given
+ * order, then ONE ncclReduce (float, sum, root 0) runs over the communicator.  The sum lands in the buffer of the
+ * context that leads RCCL rank 0 (d_buffers[0] of the process with first_rank 0); other buffers are left modified.
+ * Asynchronous on the leaders' streams. */
+int rt_reduce_to_root(rt_group* group, float* const* d_buffers, uint64_t count, void* const* streams);
+
 /* ---- device-memory helpers for callers that do not link the HIP runtime ---- */
 int rt_device_alloc(rt_context* ctx, uint64_t bytes, void** d_ptr);
 int rt_device_free(rt_context* ctx, void* d_ptr);

@@ -43,6 +43,7 @@ OPT_WF_BLOCK = 15
 OPT_WF_LANES = 16
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
+GROUP_ID_BYTES = 128
 
 
 class RtObject(C.Structure):
@@ -62,6 +63,7 @@ EXPORTS = [
     "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_raytrace_static", "rt_post_process", "rt_primary_rays",
     "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_device_alloc", "rt_device_free",
     "rt_device_zero", "rt_copy_to_host", "rt_copy_to_device", "rt_synchronize",
+    "rt_get_device", "rt_partition_samples", "rt_group_unique_id", "rt_group_create", "rt_group_destroy", "rt_reduce_to_root",
 ]
 
 _lib = None
@@ -112,6 +114,12 @@ def load():
         "rt_copy_to_host": [vp, vp, vp, u64],
         "rt_copy_to_device": [vp, vp, vp, u64],
         "rt_synchronize": [vp],
+        "rt_get_device": [vp, C.POINTER(i32)],
+        "rt_partition_samples": [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)],
+        "rt_group_unique_id": [vp],
+        "rt_group_create": [C.POINTER(vp), i32, i32, i32, vp, C.POINTER(vp)],
+        "rt_group_destroy": [vp],
+        "rt_reduce_to_root": [vp, C.POINTER(vp), u64, C.POINTER(vp)],
     }
     for name, args in protos.items():
         fn = getattr(lib, name)
@@ -176,6 +184,11 @@ class Context:
 
     def set_option(self, opt, value):
         check(self.lib.rt_set_option(self.h, opt, value))
+
+    def device(self):
+        d = C.c_int()
+        check(self.lib.rt_get_device(self.h, C.byref(d)))
+        return d.value
 
     def upload_scene(self, objects, materials, textures=()):
         """objects: list of (triangles TRIANGLE_DTYPE, nodes NODE_DTYPE); materials: MATERIAL_DTYPE array;
@@ -259,3 +272,51 @@ class Context:
     def to_device(self, ptr, array):
         array = np.ascontiguousarray(array)
         check(self.lib.rt_copy_to_device(self.h, ptr, array.ctypes.data, array.nbytes))
+
+
+def partition_samples(n_samples, semantic_batch, parts, part):
+    """rt_partition_samples -> (first_sample, count) of `part`."""
+    first, count = C.c_int(), C.c_int()
+    check(load().rt_partition_samples(n_samples, semantic_batch, parts, part, C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
+def group_unique_id():
+    """rt_group_unique_id -> 128 bytes to hand to every process of the world."""
+    buf = (C.c_uint8 * GROUP_ID_BYTES)()
+    check(load().rt_group_unique_id(buf))
+    return bytes(buf)
+
+
+class Group:
+    """rt_group over the contexts this process drives (RCCL communicator over their distinct devices)."""
+
+    def __init__(self, contexts, first_rank=0, world=None, unique_id=None):
+        self.lib = load()
+        self.n = len(contexts)
+        arr = (C.c_void_p * self.n)(*[c.h for c in contexts])
+        if world is None:
+            world = len({c.device() for c in contexts})
+        idbuf = None
+        if unique_id is not None:
+            assert len(unique_id) == GROUP_ID_BYTES
+            idbuf = (C.c_uint8 * GROUP_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        check(self.lib.rt_group_create(arr, self.n, first_rank, world, idbuf, C.byref(h)))
+        self.h = h
+
+    def reduce_to_root(self, d_buffers, count, streams=None):
+        bufs = (C.c_void_p * self.n)(*d_buffers)
+        st = (C.c_void_p * self.n)(*streams) if streams is not None else None
+        check(self.lib.rt_reduce_to_root(self.h, bufs, count, st))
+
+    def close(self):
+        if self.h:
+            self.lib.rt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -780,6 +780,13 @@ static int upload_vec(const std::vector<T>& v, void** d, uint64_t& bytes_total) 
 extern "C" {
 
 const char* rt_last_error(void) { return g_last_error.c_str(); }
+int rt_set_last_error_(int code, const char* message) { return fail(code, message ? message : ""); }   // for the library's other source files
+
+int rt_get_device(rt_context* ctx, int* device) {
+    if (!ctx || !device) return fail(RT_ERR_INVALID, "rt_get_device: null argument");
+    *device = ctx->device;
+    return RT_OK;
+}
 int rt_abi_version(void) { return RTCORE_ABI_VERSION; }
 
 int rt_build_bvh(const rt_triangle* triangles, int n_triangles, rt_bvh_node* nodes_out, int capacity) {

@@ -1,4 +1,9 @@
-"""The multi-rank path on CPU: gloo, world size 2, the oracle standing in for the kernel."""
+"""The multi-rank plumbing on CPU: rt_partition_samples (library, through the C ABI) and a world-size-2 gloo job.
+
+What this covers: the partition (every sample once, whole batches), and that frames traced for the two partitions add up
+to the one-rank frame within float-summation tolerance.  The frames here come from the CPU oracle, because this
+container has no GPU; the kernels going through the same split and through rt_reduce_to_root (RCCL) are covered on the
+GPU box by tests/test_gpu_multi.py."""
 import os
 import socket
 
@@ -43,7 +48,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import oracle as orc
     from raytrace_amd import scene
-    from raytrace_amd.dist import partition_samples, reduce_to_root
+    from raytrace_amd.dist import partition_samples
     dist.init_process_group("gloo", rank=rank, world_size=world)
     asm = scene.material_box(width=24, height=16, n_samples=16)
     objs = scene.finalize(asm, orc.OracleBackend())
@@ -52,7 +57,7 @@ def _worker(rank, world, port, q):
     first, count = partition_samples(16, 4, world, rank)
     acc, _ = sc.render(p, first, count)
     t = torch.from_numpy(acc)
-    reduce_to_root(t, 0)
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
     if rank == 0:
         q.put(t.numpy().copy())
     dist.barrier()
