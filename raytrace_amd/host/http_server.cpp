@@ -51,16 +51,35 @@ bool send_all(int fd, const char* p, size_t n) {
     return true;
 }
 
-void reply(int fd, const HttpResponse& r) {
+void send_reply(int fd, const HttpReply& r) {
     char head[256];
     const int n = std::snprintf(head, sizeof head, "HTTP/1.1 %d %s\r\nContent-Type: %s\r\nContent-Length: %zu\r\nConnection: close\r\n\r\n",
-                                r.status, reason(r.status), r.content_type.c_str(), r.body.size());
+                                r.status, reason(r.status), r.type.c_str(), r.body.size());
     if (send_all(fd, head, size_t(n))) send_all(fd, r.body.data(), r.body.size());
 }
 
 }  // namespace
 
-void HttpServer::serve(int fd) {
+void HttpServer::route(const std::string& method, const std::string& path, HttpRoute action) {
+    table_.push_back(Entry{method, path, action});
+}
+
+// The table first; then, for GET, a plain file below the directory (no ".." anywhere in the path).
+HttpReply HttpServer::answer(const HttpRequest& request) const {
+    for (const Entry& e : table_)
+        if (e.method == request.method && e.path == request.path) return e.action(request);
+    if (request.method == "GET" && !directory_.empty() && request.path.size() > 1 && request.path.find("..") == std::string::npos) {
+        const std::string file = directory_ + request.path;
+        struct stat st;
+        std::ifstream in(file.c_str(), std::ios::binary);
+        if (::stat(file.c_str(), &st) == 0 && S_ISREG(st.st_mode) && in)
+            return HttpReply::of(mime_of(file), std::string(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>()));
+    }
+    return HttpReply::text("Not Found", 404);
+}
+
+// Reads one request from the connection and answers it.
+void HttpServer::converse(int fd) const {
     timeval tv = {5, 0};
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
     std::string buf;
@@ -72,12 +91,11 @@ void HttpServer::serve(int fd) {
         buf.append(chunk, size_t(k));
         head_end = buf.find("\r\n\r\n");
     }
-    HttpResponse res;
-    if (head_end == std::string::npos) { res.status = 400; res.body = "Bad Request"; reply(fd, res); return; }
+    if (head_end == std::string::npos) { send_reply(fd, HttpReply::text("Bad Request", 400)); return; }
     HttpRequest req;
     {
         const size_t sp1 = buf.find(' '), sp2 = sp1 == std::string::npos ? sp1 : buf.find(' ', sp1 + 1);
-        if (sp2 == std::string::npos || sp2 > buf.find("\r\n")) { res.status = 400; res.body = "Bad Request"; reply(fd, res); return; }
+        if (sp2 == std::string::npos || sp2 > buf.find("\r\n")) { send_reply(fd, HttpReply::text("Bad Request", 400)); return; }
         req.method = buf.substr(0, sp1);
         req.path = buf.substr(sp1 + 1, sp2 - sp1 - 1);
         const size_t q = req.path.find('?');
@@ -91,7 +109,7 @@ void HttpServer::serve(int fd) {
         const size_t p = lower.find("\r\ncontent-length:");
         if (p != std::string::npos) content_length = size_t(std::strtoul(lower.c_str() + p + 17, nullptr, 10));
     }
-    if (content_length > (1u << 20)) { res.status = 413; res.body = "Payload Too Large"; reply(fd, res); return; }
+    if (content_length > (1u << 20)) { send_reply(fd, HttpReply::text("Payload Too Large", 413)); return; }
     req.body = buf.substr(head_end + 4);
     while (req.body.size() < content_length) {
         const ssize_t k = ::recv(fd, chunk, sizeof chunk, 0);
@@ -99,29 +117,10 @@ void HttpServer::serve(int fd) {
         req.body.append(chunk, size_t(k));
     }
     req.body.resize(std::min(req.body.size(), content_length));
-
-    auto it = handlers_.find(req.method + " " + req.path);
-    if (it != handlers_.end()) {
-        it->second(req, res);
-    } else if (req.method == "GET" && !base_dir_.empty() && req.path.find("..") == std::string::npos && req.path.size() > 1) {
-        const std::string file = base_dir_ + req.path;
-        struct stat st;
-        std::ifstream f(file.c_str(), std::ios::binary);
-        if (::stat(file.c_str(), &st) == 0 && S_ISREG(st.st_mode) && f) {
-            res.body.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            res.content_type = mime_of(file);
-        } else {
-            res.status = 404;
-            res.body = "Not Found";
-        }
-    } else {
-        res.status = 404;
-        res.body = "Not Found";
-    }
-    reply(fd, res);
+    send_reply(fd, answer(req));
 }
 
-bool HttpServer::listen(const std::string& address, int port) {
+bool HttpServer::serve(const std::string& address, int port) {
     addrinfo hints;
     std::memset(&hints, 0, sizeof hints);
     hints.ai_family = AF_INET;
@@ -138,9 +137,8 @@ bool HttpServer::listen(const std::string& address, int port) {
     const bool ok = ::bind(fd, info->ai_addr, info->ai_addrlen) == 0 && ::listen(fd, 16) == 0;
     freeaddrinfo(info);
     if (!ok) { ::close(fd); return false; }
-    listen_fd_.store(fd);
     while (!stopping_.load()) {
-        // wake up regularly so that stop() is noticed even when nobody connects
+        // wake up regularly so that shut_down() is noticed even when nobody connects
         fd_set set;
         FD_ZERO(&set);
         FD_SET(fd, &set);
@@ -149,15 +147,12 @@ bool HttpServer::listen(const std::string& address, int port) {
         if (ready <= 0) continue;
         const int client = ::accept(fd, nullptr, nullptr);
         if (client < 0) continue;
-        serve(client);
+        converse(client);
         ::shutdown(client, SHUT_RDWR);
         ::close(client);
     }
     ::close(fd);
-    listen_fd_.store(-1);
     return true;
 }
-
-void HttpServer::stop() { stopping_.store(true); }
 
 }  // namespace rth

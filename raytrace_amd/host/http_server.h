@@ -1,15 +1,15 @@
 // http_server.h -- the small part of HTTP/1.1 the render server needs, over POSIX sockets.
 //
 // Upstream uses cpp-httplib (third/httplib.h) for six routes and one static directory (csrc/server.cpp:36-113).
-// This server handles one request per connection ("Connection: close"), GET and POST with Content-Length, exact-path
-// handlers, and GET of plain files below a base directory.
+// This server handles one request per connection ("Connection: close"), GET and POST with Content-Length, a table of
+// exact (method, path) routes, and GET of plain files below one directory.
 #ifndef RT_HTTP_SERVER_H
 #define RT_HTTP_SERVER_H
 
 #include <atomic>
 #include <functional>
-#include <map>
 #include <string>
+#include <vector>
 
 namespace rth {
 
@@ -17,29 +17,31 @@ struct HttpRequest {
     std::string method, path, body;
 };
 
-struct HttpResponse {
-    int status = 200;
-    std::string content_type = "text/plain";
-    std::string body;
-    void set_content(const std::string& b, const std::string& type) { body = b; content_type = type; }
+struct HttpReply {
+    int status;
+    std::string type, body;
+    static HttpReply text(const std::string& b, int status = 200) { return HttpReply{status, "text/plain", b}; }
+    static HttpReply of(const std::string& type, const std::string& b) { return HttpReply{200, type, b}; }
 };
 
+// A route answers a request; returning is all it does (a route that wants the server to end calls shut_down()).
+typedef std::function<HttpReply(const HttpRequest&)> HttpRoute;
+
 class HttpServer {
-    typedef std::function<void(const HttpRequest&, HttpResponse&)> Handler;
-    std::map<std::string, Handler> handlers_;      // key = "METHOD path"
-    std::string base_dir_;
-    std::atomic<int> listen_fd_;
-    std::atomic_bool stopping_;
-
-    void serve(int fd);
-
 public:
-    HttpServer() : listen_fd_(-1), stopping_(false) {}
-    void Get(const std::string& path, Handler h) { handlers_["GET " + path] = h; }
-    void Post(const std::string& path, Handler h) { handlers_["POST " + path] = h; }
-    void set_base_dir(const std::string& dir) { base_dir_ = dir; }
-    bool listen(const std::string& address, int port);   // blocks until stop(); false if the socket cannot be set up
-    void stop();                                          // may be called from a handler
+    void route(const std::string& method, const std::string& path, HttpRoute action);
+    void files_from(const std::string& directory) { directory_ = directory; }   // GET of anything else looks here
+    bool serve(const std::string& address, int port);    // blocks until shut_down(); false if the socket cannot be set up
+    void shut_down() { stopping_.store(true); }           // may be called from a route
+
+private:
+    struct Entry { std::string method, path; HttpRoute action; };
+    std::vector<Entry> table_;
+    std::string directory_;
+    std::atomic_bool stopping_{false};
+
+    HttpReply answer(const HttpRequest& request) const;
+    void converse(int fd) const;
 };
 
 }  // namespace rth

@@ -139,12 +139,17 @@ int SceneLoader::load_object(std::istream& file) {
 
     std::cout << "Loading object " << objfilename << std::endl;
     if (simple_material) std::cout << "!   Simple Material type: " << kMaterialTypeName[type] << std::endl;
-    ObjModel model;
-    if (!load_obj(objfilename, mtldir, model)) {                  // :110-119
-        if (!model.error.empty()) std::cerr << "Error: " << model.error << std::endl;
-        return -1;
+    std::shared_ptr<ObjModel>& parsed = parsed_[objfilename + "\n" + mtldir];
+    if (!parsed) {
+        parsed = std::make_shared<ObjModel>();
+        if (!load_obj(objfilename, mtldir, *parsed)) {            // :110-119
+            if (!parsed->error.empty()) std::cerr << "Error: " << parsed->error << std::endl;
+            parsed.reset();
+            return -1;
+        }
+        if (!parsed->warning.empty()) std::cerr << "Warning: " << parsed->warning << std::endl;
     }
-    if (!model.warning.empty()) std::cerr << "Warning: " << model.warning << std::endl;
+    const ObjModel& model = *parsed;
     const int material_offset = int(materials_.size());
     if (model.shapes.empty()) {
         std::cerr << "Error: No shapes in object file" << std::endl;
@@ -269,6 +274,7 @@ int SceneLoader::load_scene(const std::string& filename) {
     objects_.clear();
     materials_.clear();
     textures_.clear();
+    parsed_.clear();
     int cur_obj = 0;
     std::ifstream file(filename.c_str());
     if (!file.is_open()) {
@@ -331,6 +337,7 @@ int SceneLoader::load_scene(const std::string& filename) {
             return -1;
         }
     }
+    parsed_.clear();                                              // the parsed model files are not needed any more
     std::cout << "\nBuilding BVH tree... ";
     for (HostObject& o : objects_) {
         o.bvh.resize(2 * o.triangles.size());

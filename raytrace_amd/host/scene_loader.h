@@ -8,12 +8,16 @@
 #define RT_SCENE_LOADER_H
 
 #include <fstream>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "rtcore.h"
 
 namespace rth {
+
+struct ObjModel;
 
 // include/common.cuh:19-33
 struct RenderConfig {
@@ -48,6 +52,9 @@ class SceneLoader {
     std::vector<rt_material> materials_;
     std::vector<HostTexture> textures_;
     RenderConfig config_;
+    // model files already read during this load_scene, by path and MTL directory: a scene that places one model many
+    // times (upstream reads the file again for every object block) reads it once
+    std::map<std::string, std::shared_ptr<ObjModel>> parsed_;
 
     int load_object(std::istream& file);
     int load_texture(const std::string& filename, rt_material& material);

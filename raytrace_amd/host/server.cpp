@@ -1,5 +1,8 @@
-// server.cpp -- bin/server <scene_file> <batch_size> <address> <port>: the interactive front end
-// (csrc/server.cpp:17-116).  Same six routes, same bodies, same static directory.
+// server.cpp -- bin/server <scene_file> <batch_size> <address> <port>: the interactive front end.
+//
+// The contract with the browser page is upstream's (csrc/server.cpp:40-107): six routes, their bodies and content
+// types, and the frames also reachable as static files.  Here the routes are rows of one table, each bound to a member
+// of the Viewer object that owns the worker; nothing else is shared between them.
 #include <signal.h>
 
 #include <cstdio>
@@ -7,90 +10,127 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
-#include <sstream>
 
 #include "http_server.h"
 #include "worker.h"
+
+namespace {
+
+bool slurp(const std::string& path, std::string& into) {
+    std::ifstream in(path.c_str(), std::ios::binary);
+    if (!in.is_open()) return false;
+    into.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
+    return true;
+}
+
+// Six comma-separated numbers, "x,y,z,alpha,beta,gamma": what the page's gyroscope code posts.  Fields that are missing
+// or not numbers stay zero.
+void six_numbers(const std::string& text, float out[6]) {
+    const char* p = text.c_str();
+    for (int k = 0; k < 6; k++) {
+        out[k] = 0.0f;
+        char* end = nullptr;
+        const float v = std::strtof(p, &end);
+        if (end == p) break;
+        out[k] = v;
+        p = end;
+        while (*p == ' ') p++;
+        if (*p != ',') break;
+        p++;
+    }
+}
+
+class Viewer {
+public:
+    Viewer(const std::string& scene_file, const std::string& static_dir, int batch_size, rth::HttpServer& http)
+        : worker_(scene_file, static_dir, batch_size), static_dir_(static_dir), http_(http) {}
+
+    void start() {
+        worker_.run();
+        worker_.force_render();
+        typedef rth::HttpReply (Viewer::*Action)(const rth::HttpRequest&);
+        static const struct { const char* method; const char* path; Action action; } rows[] = {
+            {"GET", "/", &Viewer::page},
+            {"POST", "/update-camera", &Viewer::move_camera},
+            {"GET", "/image", &Viewer::newest_frame},
+            {"POST", "/reset-camera", &Viewer::home_camera},
+            {"GET", "/camera-pos", &Viewer::where},
+            {"GET", "/stop", &Viewer::quit},
+        };
+        for (const auto& row : rows) {
+            const Action action = row.action;
+            http_.route(row.method, row.path, [this, action](const rth::HttpRequest& request) { return (this->*action)(request); });
+        }
+        http_.files_from(static_dir_);
+    }
+
+private:
+    rth::Worker worker_;
+    std::string static_dir_;
+    rth::HttpServer& http_;
+
+    rth::HttpReply page(const rth::HttpRequest&) {
+        std::string html;
+        if (!slurp(static_dir_ + "/index.html", html)) return rth::HttpReply::text("File not found", 404);
+        std::cout << "Serving index.html" << std::endl;
+        return rth::HttpReply::of("text/html", html);
+    }
+
+    rth::HttpReply move_camera(const rth::HttpRequest& request) {
+        float v[6];
+        six_numbers(request.body, v);
+        worker_.update_camera(rt_float3{v[0], v[1], v[2]}, rt_float3{v[3], v[4], v[5]});
+        const rt_float3 at = worker_.config().camera_pos;
+        std::cout << "Camera updated to " << at.x << "," << at.y << "," << at.z << std::endl;
+        return rth::HttpReply::text("updated");
+    }
+
+    rth::HttpReply newest_frame(const rth::HttpRequest&) {
+        char name[rth::MaxFilenameLength];
+        worker_.get_output_filename(name);
+        std::string png;
+        if (!name[0] || !slurp(name, png)) return rth::HttpReply::text("File not found", 404);
+        return rth::HttpReply::of("image/png", png);
+    }
+
+    rth::HttpReply home_camera(const rth::HttpRequest&) {
+        worker_.reset_camera();
+        return rth::HttpReply::text("Camera reset");
+    }
+
+    rth::HttpReply where(const rth::HttpRequest&) {
+        const rt_float3 at = worker_.config().camera_pos;
+        char text[128];
+        std::snprintf(text, sizeof text, "%f,%f,%f", at.x, at.y, at.z);
+        return rth::HttpReply::text(text);
+    }
+
+    rth::HttpReply quit(const rth::HttpRequest&) {
+        worker_.stop();
+        http_.shut_down();
+        std::cout << "Server stopped" << std::endl;
+        return rth::HttpReply::text("Server stopped");
+    }
+};
+
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc != 5) {
         std::cerr << "Usage: " << argv[0] << " <scene_file> <batch_size> <address> <port>" << std::endl;
         return 0;
     }
-    const std::string scene_file = argv[1];
-    const int batch_size = std::atoi(argv[2]);
+    // RT_STATIC_DIR moves the directory that holds index.html and receives the frames (upstream: fixed)
+    const char* moved = std::getenv("RT_STATIC_DIR");
+    const std::string static_dir = moved ? moved : "./assets/static";
+    signal(SIGPIPE, SIG_IGN);           // a client that goes away must not end the process
+    rth::HttpServer http;
+    Viewer viewer(argv[1], static_dir, std::atoi(argv[2]), http);
+    viewer.start();
     const std::string address = argv[3];
     const int port = std::atoi(argv[4]);
-    // RT_STATIC_DIR moves the directory that holds index.html and receives the frames (upstream: fixed)
-    const char* dir_env = std::getenv("RT_STATIC_DIR");
-    const std::string output_dir = dir_env ? dir_env : "./assets/static";
-    const std::string index_file = output_dir + "/index.html";
-    rth::Worker worker(scene_file, output_dir, batch_size);
-    worker.run();
-    signal(SIGPIPE, SIG_IGN);           // a client that goes away must not end the process
-    worker.force_render();
-
-    rth::HttpServer svr;
-    svr.Get("/", [index_file](const rth::HttpRequest&, rth::HttpResponse& res) {
-        std::ifstream file(index_file.c_str());
-        if (!file.is_open()) {
-            res.status = 404;
-            res.set_content("File not found", "text/plain");
-            return;
-        }
-        const std::string content((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
-        res.set_content(content, "text/html");
-        std::cout << "Serving index.html" << std::endl;
-    });
-    svr.set_base_dir(output_dir);
-
-    // body "x,y,z,alpha,beta,gamma": position (ignored by the worker) and orientation angles in degrees
-    svr.Post("/update-camera", [&](const rth::HttpRequest& req, rth::HttpResponse& res) {
-        rt_float3 delta_pos = {0.0f, 0.0f, 0.0f}, delta_dir = {0.0f, 0.0f, 0.0f};
-        std::istringstream body(req.body);
-        char comma;
-        body >> delta_pos.x >> comma >> delta_pos.y >> comma >> delta_pos.z >> comma;
-        body >> delta_dir.x >> comma >> delta_dir.y >> comma >> delta_dir.z;
-        worker.update_camera(delta_pos, delta_dir);
-        res.set_content("updated", "text/plain");
-        const rth::RenderConfig& config = worker.config();
-        std::cout << "Camera updated to " << config.camera_pos.x << "," << config.camera_pos.y << "," << config.camera_pos.z << std::endl;
-    });
-
-    svr.Get("/image", [&](const rth::HttpRequest&, rth::HttpResponse& res) {
-        char filename[rth::MaxFilenameLength];
-        worker.get_output_filename(filename);
-        std::ifstream file(filename, std::ios::binary);
-        if (!file.is_open()) {
-            res.status = 404;
-            res.set_content("File not found", "text/plain");
-            return;
-        }
-        const std::string content((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
-        res.set_content(content, "image/png");
-    });
-
-    svr.Post("/reset-camera", [&](const rth::HttpRequest&, rth::HttpResponse& res) {
-        worker.reset_camera();
-        res.set_content("Camera reset", "text/plain");
-    });
-
-    svr.Get("/camera-pos", [&](const rth::HttpRequest&, rth::HttpResponse& res) {
-        const rth::RenderConfig& config = worker.config();
-        char buffer[128];
-        std::snprintf(buffer, sizeof buffer, "%f,%f,%f", config.camera_pos.x, config.camera_pos.y, config.camera_pos.z);
-        res.set_content(buffer, "text/plain");
-    });
-
-    svr.Get("/stop", [&](const rth::HttpRequest&, rth::HttpResponse& res) {
-        worker.stop();
-        svr.stop();
-        std::cout << "Server stopped" << std::endl;
-        res.set_content("Server stopped", "text/plain");
-    });
-
     std::cout << "Starting server at " << address << ":" << port << std::endl;
-    if (!svr.listen(address, port)) {
+    if (!http.serve(address, port)) {
         std::cerr << "Failed to start server" << std::endl;
         return 1;
     }

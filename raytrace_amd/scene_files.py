@@ -93,57 +93,59 @@ def write_obj(model, obj_path, mtl_name=None, tex_prefix="tex"):
                     write_png_rgb(os.path.join(directory, tex_file), tex[::-1, :, :3])      # stored bottom-up, files are top-down
                     f.write("map_Kd %s\n" % tex_file)
                 f.write("\n")
+    # Vertex data goes out through numpy ("%.9g" is the shortest text that round-trips every binary32 value), faces in
+    # runs of one material; the text is the same as a line-by-line writer would produce.
     nv = nt = nn = 0
     current = None          # material name in force
-    for shp in model.shapes:
-        lines.append("o %s" % shp.name)
-        n = len(shp)
-        for t in range(n):
-            for j in range(3):
-                p = shp.pos[t, j]
-                lines.append("v %s %s %s" % (_g(p[0]), _g(p[1]), _g(p[2])))
-        if shp.has_uvs:
-            for t in range(n):
-                for j in range(3):
-                    lines.append("vt %s %s" % (_g(shp.uv[t, j, 0]), _g(shp.uv[t, j, 1])))
-        if shp.has_normals:
-            for t in range(n):
-                for j in range(3):
-                    q = shp.nrm[t, j]
-                    lines.append("vn %s %s %s" % (_g(q[0]), _g(q[1]), _g(q[2])))
-        for t in range(n):
-            m = int(shp.mtl[t])
-            name = model.mtls[m]["name"] if m >= 0 else None
-            if name != current and (name is not None or current is not None):
-                lines.append("usemtl %s" % (name if name is not None else "__none__"))     # an unknown name means "no material"
-                current = name
-            corners = []
-            for j in range(3):
-                v = nv + 3 * t + j + 1
-                vt = (nt + 3 * t + j + 1) if shp.has_uvs else None
-                vn = (nn + 3 * t + j + 1) if shp.has_normals else None
-                if vt and vn:
-                    corners.append("%d/%d/%d" % (v, vt, vn))
-                elif vt:
-                    corners.append("%d/%d" % (v, vt))
-                elif vn:
-                    corners.append("%d//%d" % (v, vn))
-                else:
-                    corners.append("%d" % v)
-            lines.append("f " + " ".join(corners))
-        nv += 3 * n
-        nt += 3 * n if shp.has_uvs else 0
-        nn += 3 * n if shp.has_normals else 0
     with open(obj_path, "w") as f:
-        f.write("\n".join(lines) + "\n")
+        f.write("".join(line + "\n" for line in lines))
+        for shp in model.shapes:
+            f.write("o %s\n" % shp.name)
+            n = len(shp)
+            np.savetxt(f, shp.pos.reshape(-1, 3).astype(np.float64), fmt="v %.9g %.9g %.9g")
+            if shp.has_uvs:
+                np.savetxt(f, shp.uv.reshape(-1, 2).astype(np.float64), fmt="vt %.9g %.9g")
+            if shp.has_normals:
+                np.savetxt(f, shp.nrm.reshape(-1, 3).astype(np.float64), fmt="vn %.9g %.9g %.9g")
+            corner = np.arange(3 * n, dtype=np.int64).reshape(n, 3) + 1
+            cols, fmt = [nv + corner], "%d"
+            if shp.has_uvs and shp.has_normals:
+                cols, fmt = [nv + corner, nt + corner, nn + corner], "%d/%d/%d"
+            elif shp.has_uvs:
+                cols, fmt = [nv + corner, nt + corner], "%d/%d"
+            elif shp.has_normals:
+                cols, fmt = [nv + corner, nn + corner], "%d//%d"
+            table = np.stack(cols, axis=2).reshape(n, -1)              # per face: corner 0's indices, corner 1's, corner 2's
+            face_fmt = "f " + " ".join([fmt] * 3)
+            mtl_ids = np.asarray(shp.mtl)
+            starts = [0] + [int(i) for i in np.nonzero(mtl_ids[1:] != mtl_ids[:-1])[0] + 1] + [n]
+            for lo, hi in zip(starts[:-1], starts[1:]):
+                if hi <= lo:
+                    continue
+                m = int(mtl_ids[lo])
+                name = model.mtls[m]["name"] if m >= 0 else None
+                if name != current and (name is not None or current is not None):
+                    f.write("usemtl %s\n" % (name if name is not None else "__none__"))     # an unknown name means "no material"
+                    current = name
+                np.savetxt(f, table[lo:hi], fmt=face_fmt)
+            nv += 3 * n
+            nt += 3 * n if shp.has_uvs else 0
+            nn += 3 * n if shp.has_normals else 0
     return mtl_name if model.mtls else None
 
 
-def write_scene(asm, directory, name="scene"):
+def write_scene(asm, directory, name="scene", relative_to=None, scene_path=None, write_models=True):
     """Writes <directory>/<name>.txt plus the model files; returns the scene file's path.  Paths inside the scene
-    file are absolute, so the file can be loaded from any working directory."""
+    file are absolute, so the file can be loaded from any working directory -- unless `relative_to` names a directory:
+    then they are relative to it (upstream's scene files name their models relative to the repository root, where
+    bin/main is started).  `scene_path` puts the text file somewhere else than the model files.  Blocks that share one
+    model object share one OBJ file.  write_models=False writes the text file only."""
     os.makedirs(directory, exist_ok=True)
     directory = os.path.abspath(directory)
+
+    def shown(path):
+        return os.path.relpath(path, os.path.abspath(relative_to)) if relative_to else path
+
     cfg = asm.config
     out = ["scene_config", "", "# written by raytrace_amd.scene_files", "",
            "max_ray_depth %d" % cfg.max_depth, "max_surface 1000000",
@@ -153,10 +155,15 @@ def write_scene(asm, directory, name="scene"):
            "fov %s" % _g(cfg.fov_deg), "gamma %s" % _g(cfg.gamma), "size %d %d" % (cfg.width, cfg.height),
            "sample_per_pixel %d" % cfg.n_samples, "background %s %s %s" % tuple(_g(x) for x in cfg.background),
            "russian_roulette %s" % _g(cfg.russian_roulette), ""]
+    written = {}
     for k, blk in enumerate(asm.blocks):
-        obj_file = os.path.join(directory, "%s_obj%d.obj" % (name, k))
-        write_obj(blk.model, obj_file)
-        out += ["object", "    path %s" % obj_file, "    mtldir %s" % directory,
+        obj_file = written.get(id(blk.model))
+        if obj_file is None:
+            obj_file = os.path.join(directory, "%s_obj%d.obj" % (name, k))
+            if write_models:
+                write_obj(blk.model, obj_file)
+            written[id(blk.model)] = obj_file
+        out += ["object", "    path %s" % shown(obj_file), "    mtldir %s" % (shown(directory) + ("/" if relative_to else "")),
                 "    position %s %s %s" % tuple(_g(x) for x in blk.position),
                 "    rotation %s %s %s" % tuple(_g(x) for x in blk.rotation),
                 "    scale %s %s %s" % tuple(_g(x) for x in blk.scale),
@@ -168,7 +175,7 @@ def write_scene(asm, directory, name="scene"):
             out += ["    # every face takes the object's own material", "    simple_material"]
         out += ["end", ""]
     out += ["end", ""]
-    path = os.path.join(directory, name + ".txt")
+    path = scene_path or os.path.join(directory, name + ".txt")
     with open(path, "w") as f:
         f.write("\n".join(out))
     return path

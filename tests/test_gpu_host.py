@@ -199,3 +199,43 @@ def test_bin_server_routes(tmp_path):
             proc.kill()
             proc.wait(timeout=10)
         log.close()
+
+
+def test_bin_main_on_several_contexts(tmp_path):
+    """RT_GPU_LIST=0,0,0: three contexts (here on one GPU) each trace their partition of the batches on a host thread of
+    their own, the library adds the buffers up (rt_reduce_to_root) and the first context post-processes with the total
+    sample count.  Same samples as the one-context frame, batch totals added in another order: a pixel may move by one
+    8-bit level where the sum sits on a rounding boundary."""
+    asm = scene.material_box(width=64, height=40, n_samples=24)
+    path = scene_files.write_scene(asm, str(tmp_path / "files"), name="split")
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, RT_SEED=str(SEED), RT_GPU_LIST="0,0,0")
+    r = subprocess.run([MAIN, path, str(out), "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 contexts on 1 GPU(s)" in r.stdout and "Image saved to" in r.stdout
+    got = scene_files.read_png_rgb(str(out / "split-output.png")).astype(int)
+    want = expected_png_pixels(asm, 4, SEED).astype(int)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+def test_bin_main_on_a_benchmark_scene_file(tmp_path):
+    """The benchmark's route through the reference's entry point: a scene file as tools/make_bench_scenes.py writes it
+    (model paths relative to the directory bin/main is started in, as in upstream's assets/scene/*.txt), here the formula-1
+    configuration at a reduced frame, detail and sample count.  The PNG equals the Python route's byte for byte."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_bench_scenes", os.path.join(ROOT, "tools", "make_bench_scenes.py"))
+    mbs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mbs)
+    path, asm = mbs.write("formula1", True, root=str(tmp_path), assembler=lambda: scene.formula1(200, 120, 8, detail=0.1, tex_size=64))
+    assert os.path.relpath(path, str(tmp_path)) == "benchmarks/scenes/scene_formula1.txt"
+    assert "path benchmarks/assets/formula1/formula1_obj0.obj" in open(path).read()
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([MAIN, "benchmarks/scenes/scene_formula1.txt", "out", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RT_SEED=str(SEED)), cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "---> done in " in r.stdout
+    got = scene_files.read_png_rgb(str(out / "scene_formula1-output.png"))
+    want = expected_png_pixels(asm, 4, SEED)
+    assert np.array_equal(got, want), f"{(got != want).any(axis=2).sum()} pixels differ"

@@ -364,3 +364,19 @@ def test_scene_errors(tmp_path, text, needle):
 def test_missing_scene_file(tmp_path):
     r, _ = load_with_cpp(str(tmp_path / "none.txt"), tmp_path)
     assert r.returncode == 1 and "Cannot open file" in r.stderr
+
+
+def test_tracked_benchmark_scene_files_are_what_the_generator_writes(tmp_path):
+    """benchmarks/scenes/*.txt are the text files tools/make_bench_scenes.py writes for the five BASELINE configurations
+    (the model files beside them are generated on demand and not tracked)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_bench_scenes", os.path.join(root, "tools", "make_bench_scenes.py"))
+    mbs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mbs)
+    assert sorted(mbs.CONFIGS) == ["formula1", "formula1_glass", "luyu", "shuttle", "stress"]
+    for name in ("luyu", "formula1_glass"):                         # two of the five; the others differ only in size
+        path, _ = mbs.write(name, False, root=str(tmp_path))
+        tracked = open(os.path.join(root, "benchmarks", "scenes", f"scene_{name}.txt")).read()
+        assert open(path).read() == tracked
+        assert "size 400 240" in tracked if name == "luyu" else "simple_material" in tracked
