@@ -45,7 +45,10 @@ bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_mod
 	@mkdir -p bin
 	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o -Lraytrace_amd -lrtcore -lz $(RPATH)
 
-$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
+$(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_build.h $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(CSRC)/rt_build.o: $(CSRC)/rt_build.hip $(CSRC)/rt_build.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(CSRC)/rt_multi.o: $(CSRC)/rt_multi.hip include/rtcore.h
@@ -54,7 +57,7 @@ $(CSRC)/rt_multi.o: $(CSRC)/rt_multi.hip include/rtcore.h
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HOSTFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/rt_kernels.o $(CSRC)/rt_host.o $(CSRC)/rt_multi.o
+$(LIB): $(CSRC)/rt_kernels.o $(CSRC)/rt_host.o $(CSRC)/rt_multi.o $(CSRC)/rt_build.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -ldl
 
 oracle:

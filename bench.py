@@ -61,7 +61,7 @@ def source_hash():
 
 
 def workload_key(args, cfg):
-    return f"{args.scene}_{cfg.width}x{cfg.height}_detail{args.detail:g}_depth{cfg.max_depth}"
+    return f"{args.scene}_{cfg.width}x{cfg.height}_detail{args.detail:g}_depth{cfg.max_depth}" + ("_gpubvh" if args.gpu_bvh else "")
 
 
 def counter_passes(key):
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
     ap.add_argument("--wf-lanes", type=int, default=0)
+    ap.add_argument("--gpu-bvh", action="store_true", help="build the scene tree on the device (RT_OPT_GPU_BVH) instead of re-packing upstream's trees")
     ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
     args = ap.parse_args()
 
@@ -154,9 +155,21 @@ def main():
     if args.depth:
         cfg.max_depth = args.depth
     t_assemble = time.time() - t0
-    objs = scene.finalize(asm, progress=(lambda i, n: log(f"  object {i}/{n} transformed, BVH built") if (i % 8 == 0 or i == n) and rank == 0 else None))
+    if args.gpu_bvh:
+        # only the transform runs on the host; the tree is built on the device from the triangle arrays
+        t_tr = time.time()
+        objs = []
+        for tri, (sc_, pos_, rot_) in zip(asm.triangles, asm.transforms):
+            t = tri.copy()
+            capi.apply_transform(t, sc_, pos_, rot_)
+            objs.append((t, None))
+        log(f"  transformed {len(objs)} objects in {time.time() - t_tr:.1f}s; the tree is built on the device")
+    else:
+        objs = scene.finalize(asm, progress=(lambda i, n: log(f"  object {i}/{n} transformed, BVH built") if (i % 8 == 0 or i == n) and rank == 0 else None))
     t_build = time.time() - t0 - t_assemble
     ctx = capi.Context(device_index)
+    if args.gpu_bvh:
+        ctx.set_option(capi.OPT_GPU_BVH, 1)
     t1 = time.time()
     ctx.upload_scene(objs, asm.materials, asm.textures)
     t_upload = time.time() - t1
@@ -193,7 +206,8 @@ def main():
     if rank == 0:
         log(f"scene {args.scene}: {stats['triangles']} triangles, {stats['objects']} objects, "
             f"{stats['device_bytes'] / 1e6:.1f} MB packed, models generated in {t_assemble:.1f}s, "
-            f"transform + BVH build {t_build:.1f}s ({os.environ.get('RT_HOST_THREADS', 'up to 16')} threads), re-pack + upload {t_upload:.1f}s")
+            f"transform + BVH build {t_build:.1f}s ({os.environ.get('RT_HOST_THREADS', 'up to 16')} threads), re-pack + upload {t_upload:.1f}s"
+            + (f"; device build {stats['gpu_build_ms']:.0f} ms + triangle copy {stats['gpu_copy_ms']:.0f} ms, stack need {stats['stack_slots']}" if args.gpu_bvh else ""))
 
     # the reduce goes through the library (rt_group_create / rt_reduce_to_root); the gloo rehearsal, whose ranks share a
     # device (RCCL takes a device once per communicator), sums through host memory instead
@@ -370,6 +384,7 @@ def main():
                                    f"{frame_spp}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
                        "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
                        "mode": args.mode or "library default (wavefront)",
+                       "tree": "built on the device (LBVH, RT_OPT_GPU_BVH)" if args.gpu_bvh else "upstream's median-split trees, re-packed",
                        "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU",
                        "reduce": reduce_via},
             "seconds_per_frame": round(ms_per_step * 1e-3 * frame_spp / (spp * world), 3),
@@ -392,7 +407,7 @@ def main():
             "source_hash": source_hash(), "workload_key": workload_key(args, cfg),
             "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.gpu_bvh:
             out["cpu_baseline"] = cpu_baseline(asm, objs, args)
             out["cpu_baseline"]["cfg1"] = cpu_cfg1(args)
         if args.save_image:

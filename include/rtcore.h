@@ -147,7 +147,13 @@ enum {
     RT_OPT_WF_LANES = 16,     /* wavefront: independent pipelines a pass's samples are split over, each on a stream of its own, so that
                                  one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);
                                  scheduling only */
-    RT_OPT_WF_BURST = 9       /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
+    RT_OPT_WF_BURST = 9,      /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
+    RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
+                                 for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
+                                 objects on the device (Morton-code LBVH, rocPRIM sorts): a load-time option for large scenes, replacing
+                                 upstream's host build (csrc/bvh.cpp:29-98).  Another tree means another visiting order: among equally
+                                 near triangles another one may win, and the rare rays for which slab test and triangle test disagree may
+                                 see another hit -- records then agree with an exhaustive search, not with upstream's walk */
 };
 
 const char* rt_last_error(void);
@@ -245,7 +251,8 @@ int rt_reset_counters(rt_context* ctx);                             /* also clea
 int rt_get_timing(rt_context* ctx, double out[8]);
 
 /* Scene statistics after upload: out[0]=triangles, [1]=packed inner nodes, [2]=max stack depth,
- * [3]=device bytes of the packed scene, [4]=objects. */
+ * [3]=device bytes of the packed scene, [4]=objects; with RT_OPT_GPU_BVH also [5]=microseconds the device build took,
+ * [6]=microseconds the copy of the triangle arrays to the device took, [7]=levels of the binary hierarchy. */
 int rt_scene_stats(rt_context* ctx, uint64_t out[8]);
 
 /* ---- multi-GPU: sample split and the sum onto the root GPU ----

@@ -41,6 +41,7 @@ OPT_WF_VOTE = 13
 OPT_WF_REFILL = 14
 OPT_WF_BLOCK = 15
 OPT_WF_LANES = 16
+OPT_GPU_BVH = 17
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 GROUP_ID_BYTES = 128
@@ -197,6 +198,10 @@ class Context:
         keep = []
         for i, (t, n) in enumerate(objects):
             t = np.ascontiguousarray(t, dtype=TRIANGLE_DTYPE)
+            if n is None:                                   # only with OPT_GPU_BVH: the tree is built on the device
+                keep.append(t)
+                objs[i] = RtObject(t.ctypes.data, None, len(t), 0)
+                continue
             n = np.ascontiguousarray(n, dtype=NODE_DTYPE)
             keep += [t, n]
             objs[i] = RtObject(t.ctypes.data, n.ctypes.data, len(t), len(n))
@@ -248,7 +253,8 @@ class Context:
     def scene_stats(self):
         out = (C.c_uint64 * 8)()
         check(self.lib.rt_scene_stats(self.h, out))
-        return {"triangles": out[0], "inner_nodes": out[1], "stack_slots": out[2], "device_bytes": out[3], "objects": out[4]}
+        return {"triangles": out[0], "inner_nodes": out[1], "stack_slots": out[2], "device_bytes": out[3], "objects": out[4],
+                "gpu_build_ms": out[5] / 1000.0, "gpu_copy_ms": out[6] / 1000.0, "gpu_binary_levels": out[7]}
 
     def synchronize(self):
         check(self.lib.rt_synchronize(self.h))

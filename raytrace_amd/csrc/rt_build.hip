@@ -1,0 +1,575 @@
+// rt_build.hip -- the scene tree built on the GPU (RT_OPT_GPU_BVH): one linear BVH over all triangles of all objects,
+// emitted straight into the layout the kernels walk (Node4 / TriIsect / TriShade / TriOrigin, rt_packed.h).
+//
+// Upstream builds one median-split tree per object on the host, single-threaded (csrc/bvh.cpp:29-98), and the default
+// upload keeps that tree node for node because the visiting order decides which of two equally near triangles wins and
+// which boxes a ray is tested against.  This builder is the load-time alternative for large scenes: a different tree
+// (so hit records are those of an exhaustive search up to the known disagreements between slab test and triangle test,
+// not upstream's bit for bit), built in a fraction of a second where the host path takes seconds.
+//
+// Steps, all on the device:
+//   1. per object the bounds of its triangles' centroids (ordered-integer atomics); sort key per triangle = object number,
+//      then the Morton code of the centroid inside its object's bounds;
+//   2. rocPRIM radix sort of (code, triangle);
+//   3. leaves = pairs of neighbours in sorted order (the walk's leaves hold one or two triangles); binary hierarchy over
+//      the leaves after Karras 2012, one thread per inner node, equal codes told apart by their position;
+//   4. boxes bottom-up (the second thread to reach a node fits it and goes on);
+//   5. the inner nodes at even depth become two-level records: numbered breadth first, larger boxes first inside a level
+//      (second radix sort), so that the records every walk starts with lead the array (the kernels keep a prefix in LDS);
+//   6. stack need bottom-up over the two-level records; the slots of a record are ordered so that the slot with the
+//      deepest subtree is visited last -- nothing waits on the stack while the walk is below it -- which keeps the
+//      stack need logarithmic even where Morton codes make the tree deep;
+//   7. triangle records in sorted order.
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_build.h"
+
+using namespace rtc;
+
+namespace {
+
+#define BUILD_BLOCK 256
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t LEAF_BIT = 0x80000000u;      // in the binary hierarchy: child is a leaf (low bits = leaf number)
+
+struct RawTri { int32_t material_id; int32_t pad; float v[3][8]; };      // rt_triangle: position 0..2, normal 3..5, uv 6..7 per vertex
+static_assert(sizeof(RawTri) == sizeof(rt_triangle), "RawTri");
+
+__device__ __forceinline__ uint32_t ordered(float f) { const uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__host__ __device__ __forceinline__ float unordered(uint32_t o) {
+    const uint32_t b = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// the object whose range [first[k], first[k+1]) holds triangle g
+__device__ __forceinline__ int object_of(const uint32_t* __restrict__ first, int n_objects, uint32_t g) {
+    int lo = 0, hi = n_objects - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// bounds[6 * k + 0..2] = min, [6 * k + 3..5] = max of the centroids of object k, as ordered integers.  A block whose
+// triangles all belong to one object (nearly all blocks) reduces in LDS and adds six atomics; a block that straddles
+// objects lets every thread add its own.
+__global__ __launch_bounds__(BUILD_BLOCK) void centroid_bounds_kernel(const RawTri* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ first,
+                                                                      int n_objects, uint32_t* bounds) {
+    __shared__ uint32_t lo[3], hi[3];
+    const uint32_t begin = blockIdx.x * BUILD_BLOCK, i = begin + threadIdx.x;
+    const uint32_t end = min(n, begin + BUILD_BLOCK) - 1;
+    const int obj_a = object_of(first, n_objects, begin), obj_b = object_of(first, n_objects, end);
+    if (threadIdx.x < 3) { lo[threadIdx.x] = 0xFFFFFFFFu; hi[threadIdx.x] = 0u; }
+    __syncthreads();
+    if (i < n) {
+        const RawTri& t = tris[i];
+        const int mine = obj_a == obj_b ? obj_a : object_of(first, n_objects, i);
+        for (int a = 0; a < 3; a++) {
+            const float c = (t.v[0][a] + t.v[1][a] + t.v[2][a]) * (1.0f / 3.0f);
+            if (!(c == c)) continue;
+            if (obj_a == obj_b) { atomicMin(&lo[a], ordered(c)); atomicMax(&hi[a], ordered(c)); }
+            else { atomicMin(&bounds[6 * mine + a], ordered(c)); atomicMax(&bounds[6 * mine + 3 + a], ordered(c)); }
+        }
+    }
+    __syncthreads();
+    if (obj_a == obj_b && threadIdx.x < 3) {
+        atomicMin(&bounds[6 * obj_a + threadIdx.x], lo[threadIdx.x]);
+        atomicMax(&bounds[6 * obj_a + 3 + threadIdx.x], hi[threadIdx.x]);
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t x) {      // 21 bits -> every third bit of 63
+    uint64_t v = x & 0x1FFFFFu;
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+// Sort key of a triangle: its object's number in the high bits, below it the Morton code of its centroid inside the
+// object's own centroid box (`bits` per axis).  The top of the hierarchy then divides the object sequence, and every
+// object gets a subtree of its own: an object's box stays as tight as upstream's per-object trees make it, and a huge
+// triangle (a ground plane) widens no box but those above its own object.
+__global__ __launch_bounds__(BUILD_BLOCK) void morton_kernel(const RawTri* __restrict__ tris, uint32_t n, const uint32_t* __restrict__ first, int n_objects,
+                                                             const uint32_t* __restrict__ bounds, int bits, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const RawTri& t = tris[i];
+    const int obj = object_of(first, n_objects, i);
+    const uint32_t* ob = bounds + 6 * obj;
+    // one cell size for all three axes (the largest extent sets it): cells are cubes, so the code's next bit halves
+    // space the same way on every axis; per-axis scaling would cut a flat object into thin slabs
+    float extent = 0.0f;
+    for (int a = 0; a < 3; a++) extent = fmaxf(extent, unordered(ob[3 + a]) - unordered(ob[a]));
+    const float cells = (float)(1u << bits);
+    uint64_t key = 0;
+    for (int a = 0; a < 3; a++) {
+        const float lo = unordered(ob[a]);
+        const float c = (t.v[0][a] + t.v[1][a] + t.v[2][a]) * (1.0f / 3.0f);
+        float u = extent > 0.0f ? (c - lo) / extent : 0.0f;
+        u = u == u ? fminf(fmaxf(u, 0.0f), 1.0f) : 0.0f;           // NaN centroids go to a corner
+        const uint32_t q = (uint32_t)fminf(u * cells, cells - 1.0f);
+        key |= spread21(q) << a;
+    }
+    keys[i] = ((uint64_t)obj << (3 * bits)) | key;
+    ids[i] = i;
+}
+
+__global__ __launch_bounds__(BUILD_BLOCK) void leaf_keys_kernel(const uint64_t* __restrict__ sorted_keys, uint32_t m, uint64_t* __restrict__ leaf_keys) {
+    const uint32_t j = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (j < m) leaf_keys[j] = sorted_keys[2 * (size_t)j];
+}
+
+// length of the common prefix of leaves i and j (equal codes: their positions decide); -1 outside the array
+__device__ __forceinline__ int prefix(const uint64_t* __restrict__ keys, int m, int i, int j) {
+    if (j < 0 || j >= m) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+struct Binary {               // the binary hierarchy over m leaves: m - 1 inner nodes, node 0 is the root
+    uint32_t* child;          // [2 * (m-1)]: left, right; LEAF_BIT | leaf number, or inner node number
+    uint32_t* parent;         // [m-1]: inner node above (NONE for the root)
+    uint32_t* leaf_parent;    // [m]
+    float* box;               // [6 * (m-1)]
+    float* leaf_box;          // [6 * m]
+    uint32_t* arrived;        // [m-1]
+    uint32_t* depth;          // [m-1]
+};
+
+__global__ __launch_bounds__(BUILD_BLOCK) void hierarchy_kernel(const uint64_t* __restrict__ keys, int m, Binary b) {
+    const int i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (i >= m - 1) return;
+    const int d = prefix(keys, m, i, i + 1) - prefix(keys, m, i, i - 1) >= 0 ? 1 : -1;
+    const int floor_prefix = prefix(keys, m, i, i - d);
+    long long reach = 2;
+    for (;;) {
+        const long long at = (long long)i + reach * d;
+        if (at < 0 || at >= m || !(prefix(keys, m, i, (int)at) > floor_prefix)) break;
+        reach *= 2;
+    }
+    long long len = 0;
+    for (long long t = reach / 2; t >= 1; t /= 2) {
+        const long long at = (long long)i + (len + t) * d;
+        if (at >= 0 && at < m && prefix(keys, m, i, (int)at) > floor_prefix) len += t;
+    }
+    const int j = (int)((long long)i + len * d);
+    const int node_prefix = prefix(keys, m, i, j);
+    long long s = 0, t = len;
+    do {
+        t = (t + 1) >> 1;
+        const long long at = (long long)i + (s + t) * d;
+        if (at >= 0 && at < m && prefix(keys, m, i, (int)at) > node_prefix) s += t;
+    } while (t > 1);
+    const int split = (int)((long long)i + s * d) + (d < 0 ? -1 : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    const uint32_t left = first == split ? (LEAF_BIT | (uint32_t)split) : (uint32_t)split;
+    const uint32_t right = last == split + 1 ? (LEAF_BIT | (uint32_t)(split + 1)) : (uint32_t)(split + 1);
+    b.child[2 * (size_t)i] = left;
+    b.child[2 * (size_t)i + 1] = right;
+    if (left & LEAF_BIT) b.leaf_parent[split] = (uint32_t)i; else b.parent[split] = (uint32_t)i;
+    if (right & LEAF_BIT) b.leaf_parent[split + 1] = (uint32_t)i; else b.parent[split + 1] = (uint32_t)i;
+    if (i == 0) b.parent[0] = NONE;
+}
+
+// Values another workgroup wrote earlier in the same launch are read and written at device scope, past the caches that
+// are private to a CU or an XCD.
+__device__ __forceinline__ float peek(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void poke(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A leaf's box is the exact min/max of its triangles' corners, as upstream's (csrc/bvh.cpp:36-47).
+__global__ __launch_bounds__(BUILD_BLOCK) void fit_kernel(const RawTri* __restrict__ tris, const uint32_t* __restrict__ sorted_ids, uint32_t n, uint32_t m, Binary b) {
+    const uint32_t j = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (j >= m) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k = 2 * j; k < 2 * j + 2 && k < n; k++) {
+        const RawTri& t = tris[sorted_ids[k]];
+        for (int c = 0; c < 3; c++)
+            for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], t.v[c][a]); hi[a] = fmaxf(hi[a], t.v[c][a]); }
+    }
+    for (int a = 0; a < 3; a++) { poke(&b.leaf_box[6 * (size_t)j + a], lo[a]); poke(&b.leaf_box[6 * (size_t)j + 3 + a], hi[a]); }
+    if (m == 1) return;
+    uint32_t node = b.leaf_parent[j];
+    while (node != NONE) {
+        __threadfence();
+        if (atomicAdd(&b.arrived[node], 1u) == 0u) return;          // the first to arrive leaves the node to the second
+        __threadfence();
+        for (int side = 0; side < 2; side++) {
+            const uint32_t c = b.child[2 * (size_t)node + side];
+            const float* src = (c & LEAF_BIT) ? b.leaf_box + 6 * (size_t)(c & ~LEAF_BIT) : b.box + 6 * (size_t)c;
+            for (int a = 0; a < 3; a++) {
+                const float l = peek(src + a), h = peek(src + 3 + a);
+                lo[a] = side == 0 ? l : fminf(lo[a], l);
+                hi[a] = side == 0 ? h : fmaxf(hi[a], h);
+            }
+        }
+        for (int a = 0; a < 3; a++) { poke(&b.box[6 * (size_t)node + a], lo[a]); poke(&b.box[6 * (size_t)node + 3 + a], hi[a]); }
+        node = b.parent[node];
+    }
+}
+
+__global__ __launch_bounds__(BUILD_BLOCK) void depth_kernel(uint32_t inner, Binary b, uint32_t* __restrict__ even_flag, uint32_t* max_depth) {
+    const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (i >= inner) return;
+    uint32_t d = 0;
+    for (uint32_t p = b.parent[i]; p != NONE; p = b.parent[p]) d++;
+    b.depth[i] = d;
+    even_flag[i] = (d & 1u) ? 0u : 1u;
+    atomicMax(max_depth, d);
+}
+
+__device__ __forceinline__ float half_area(const float* bx) {
+    const float dx = bx[3] - bx[0], dy = bx[4] - bx[1], dz = bx[5] - bx[2];
+    const float a = dx * dy + dy * dz + dz * dx;
+    return (a == a && a > 0.0f) ? a : 0.0f;
+}
+
+// even-depth inner nodes, compacted: their sort key (level, then falling box area) and their number
+__global__ __launch_bounds__(BUILD_BLOCK) void even_keys_kernel(uint32_t inner, Binary b, const uint32_t* __restrict__ even_flag, const uint32_t* __restrict__ even_pos,
+                                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (i >= inner || !even_flag[i]) return;
+    const uint32_t at = even_pos[i];
+    keys[at] = ((uint64_t)(b.depth[i] >> 1) << 32) | (uint64_t)(0xFFFFFFFFu - __float_as_uint(half_area(b.box + 6 * (size_t)i)));
+    nodes[at] = i;
+}
+
+__global__ __launch_bounds__(BUILD_BLOCK) void rank_kernel(uint32_t n4, const uint32_t* __restrict__ sorted_nodes, uint32_t* __restrict__ rank_of) {
+    const uint32_t r = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (r < n4) rank_of[sorted_nodes[r]] = r;
+}
+
+struct Records {
+    Node4* nodes4;
+    uint32_t* parent4;        // [n4]
+    uint32_t* inner_slots;    // [n4] slots that lead to another record
+    uint32_t* arrived4;       // [n4]
+    uint32_t* need4;          // [n4] stack entries a walk below the record can have waiting at once
+};
+
+__device__ __forceinline__ uint32_t leaf_ref(uint32_t leaf, uint32_t n) {
+    const uint32_t first = 2 * leaf;
+    return REF_LEAF | first | (first + 1 < n ? REF_PAIR : 0u);
+}
+
+// One thread per two-level record (in its final place): the node's children, or their children where a child is an inner node.
+__global__ __launch_bounds__(BUILD_BLOCK) void emit_records_kernel(uint32_t n4, uint32_t n, const uint32_t* __restrict__ sorted_nodes,
+                                                                   const uint32_t* __restrict__ rank_of, Binary b, Records rec, int upper_first) {
+    const uint32_t r = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (r >= n4) return;
+    const uint32_t node = sorted_nodes[r];
+    Node4 out;
+    uint32_t used = 0, inner = 0;
+    auto put = [&](uint32_t c) {
+        const float* bx = (c & LEAF_BIT) ? b.leaf_box + 6 * (size_t)(c & ~LEAF_BIT) : b.box + 6 * (size_t)c;
+        for (int a = 0; a < 6; a++) out.box[used][a] = bx[a];
+        if (c & LEAF_BIT) {
+            out.ref[used] = leaf_ref(c & ~LEAF_BIT, n);
+        } else {
+            const uint32_t rr = rank_of[c];
+            out.ref[used] = rr;
+            rec.parent4[rr] = r;
+            inner++;
+        }
+        used++;
+    };
+    // a node's right child holds the higher Morton codes; slot 0 is visited first
+    for (int turn = 0; turn < 2; turn++) {
+        const int side = upper_first ? 1 - turn : turn;
+        const uint32_t c = b.child[2 * (size_t)node + side];
+        if (c & LEAF_BIT) put(c);
+        else { put(b.child[2 * (size_t)c + (upper_first ? 1 : 0)]); put(b.child[2 * (size_t)c + (upper_first ? 0 : 1)]); }
+    }
+    for (uint32_t k = used; k < 4; k++) {
+        for (int a = 0; a < 3; a++) { out.box[k][a] = INFINITY; out.box[k][3 + a] = -INFINITY; }
+        out.ref[k] = REF_NONE;
+    }
+    for (int k = 0; k < 4; k++) out.pad[k] = 0;
+    rec.nodes4[r] = out;
+    rec.inner_slots[r] = inner;
+    if (r == 0) rec.parent4[0] = NONE;
+}
+
+// Stack need, bottom-up.  While the walk is below slot i of a record, the later slots may all wait on the stack: need =
+// max over slots of (slots behind it + need below it).  The slots are re-ordered by rising need, so the deepest subtree
+// comes last and adds nothing of its own record.  A record is finished by whichever thread brings the last of its inner slots.
+__global__ __launch_bounds__(BUILD_BLOCK) void need_kernel(uint32_t n4, Records rec, int reorder) {
+    const uint32_t start = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (start >= n4 || rec.inner_slots[start] != 0) return;
+    uint32_t r = start;
+    for (;;) {
+        Node4 nd = rec.nodes4[r];
+        uint32_t need[4], used = 0;
+        for (int k = 0; k < 4; k++) {
+            if (nd.ref[k] == REF_NONE) continue;
+            need[k] = (nd.ref[k] & REF_LEAF) ? 0u : peek(&rec.need4[nd.ref[k]]);
+            used++;
+        }
+        // insertion sort of the used slots (they are the first `used`) by need, stable
+        for (uint32_t a = 1; reorder && a < used; a++)
+            for (uint32_t k = a; k > 0 && need[k - 1] > need[k]; k--) {
+                const uint32_t tn = need[k]; need[k] = need[k - 1]; need[k - 1] = tn;
+                const uint32_t tr = nd.ref[k]; nd.ref[k] = nd.ref[k - 1]; nd.ref[k - 1] = tr;
+                for (int c = 0; c < 6; c++) { const float tb = nd.box[k][c]; nd.box[k][c] = nd.box[k - 1][c]; nd.box[k - 1][c] = tb; }
+            }
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < used; k++) total = max(total, used - 1 - k + need[k]);
+        rec.nodes4[r] = nd;
+        poke(&rec.need4[r], total);
+        const uint32_t up = rec.parent4[r];
+        if (up == NONE) return;
+        __threadfence();
+        if (atomicAdd(&rec.arrived4[up], 1u) + 1u != rec.inner_slots[up]) return;
+        __threadfence();
+        r = up;
+    }
+}
+
+__global__ __launch_bounds__(BUILD_BLOCK) void emit_triangles_kernel(const RawTri* __restrict__ tris, const uint32_t* __restrict__ sorted_ids, uint32_t n,
+                                                                     const uint32_t* __restrict__ object_first, int n_objects,
+                                                                     TriIsect* __restrict__ isect, TriShade* __restrict__ shade, TriOrigin* __restrict__ origin) {
+    const uint32_t p = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t g = sorted_ids[p];
+    const RawTri& t = tris[g];
+    TriIsect r;
+    for (int a = 0; a < 3; a++) {
+        r.v0[a] = t.v[0][a];
+        r.e1[a] = t.v[1][a] + (-t.v[0][a]);           // the two edge subtractions of cuda/raytrace.cu:25-26, done once
+        r.e2[a] = t.v[2][a] + (-t.v[0][a]);
+        r.pad[a] = 0;
+    }
+    isect[p] = r;
+    TriShade s;
+    for (int a = 0; a < 3; a++) { s.n0[a] = t.v[0][3 + a]; s.n1[a] = t.v[1][3 + a]; s.n2[a] = t.v[2][3 + a]; }
+    for (int a = 0; a < 2; a++) { s.uv0[a] = t.v[0][6 + a]; s.uv1[a] = t.v[1][6 + a]; s.uv2[a] = t.v[2][6 + a]; }
+    s.material_id = t.material_id;
+    shade[p] = s;
+    const int obj = object_of(object_first, n_objects, g);
+    origin[p] = TriOrigin{obj, (int32_t)(g - object_first[obj])};
+}
+
+// The triangle a walk that enters every box tests last: the last used slot all the way down, then the leaf's last triangle.
+__global__ void last_triangle_kernel(const Node4* __restrict__ nodes4, uint32_t root_ref, uint32_t* out) {
+    uint32_t ref = root_ref;
+    for (int guard = 0; guard < 4096 && ref != REF_NONE && !(ref & REF_LEAF); guard++) {
+        uint32_t last = REF_NONE;
+        for (int k = 0; k < 4; k++) if (nodes4[ref].ref[k] != REF_NONE) last = nodes4[ref].ref[k];
+        ref = last;
+    }
+    *out = (ref == REF_NONE || !(ref & REF_LEAF)) ? REF_NONE : (ref & REF_MASK) + ((ref & REF_PAIR) ? 1u : 0u);
+}
+
+struct Scratch {              // device allocations that live only during the build
+    std::vector<void*> held;
+    ~Scratch() { for (void* p : held) (void)hipFree(p); }
+    template <class T> hipError_t get(T** p, size_t count) {
+        const hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) held.push_back(*p);
+        return e;
+    }
+};
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + BUILD_BLOCK - 1) / BUILD_BLOCK); }
+
+}  // namespace
+
+namespace rtc {
+
+#define BUILD_TRY(expr)                                                            \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); release_device_scene(out); return -1; } \
+    } while (0)
+
+void release_device_scene(DeviceScene& s) {
+    void** ptrs[] = {&s.nodes4, &s.isect, &s.shade, &s.origin};
+    for (void** p : ptrs) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+}
+
+int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& out, std::string& err) {
+    out = DeviceScene();
+    uint64_t total = 0;
+    std::vector<uint32_t> first(n_objects + 1, 0);
+    for (int i = 0; i < n_objects; i++) {
+        if (!objects[i].triangles || objects[i].n_triangles <= 0) { err = "object " + std::to_string(i) + ": no triangles"; return -1; }
+        first[i] = (uint32_t)total;
+        total += (uint64_t)objects[i].n_triangles;
+        if (total > (uint64_t)REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
+    }
+    first[n_objects] = (uint32_t)total;
+    const uint32_t n = (uint32_t)total, m = (n + 1) / 2, inner = m - 1;
+    Scratch tmp;
+    hipEvent_t ev[3];
+    for (hipEvent_t& e : ev) BUILD_TRY(hipEventCreate(&e));
+    struct EventGuard { hipEvent_t* ev; ~EventGuard() { for (int k = 0; k < 3; k++) (void)hipEventDestroy(ev[k]); } } guard{ev};
+
+    // ---- the triangles as the caller holds them, object after object ----
+    RawTri* d_tris = nullptr;
+    uint32_t* d_first = nullptr;
+    BUILD_TRY(tmp.get(&d_tris, n));
+    BUILD_TRY(tmp.get(&d_first, (size_t)n_objects + 1));
+    BUILD_TRY(hipEventRecord(ev[0], nullptr));
+    for (int i = 0; i < n_objects; i++)
+        BUILD_TRY(hipMemcpyAsync(d_tris + first[i], objects[i].triangles, (size_t)objects[i].n_triangles * sizeof(RawTri), hipMemcpyHostToDevice, nullptr));
+    BUILD_TRY(hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+    BUILD_TRY(hipEventRecord(ev[1], nullptr));
+
+    // ---- outputs ----
+    BUILD_TRY(hipMalloc(&out.isect, ((size_t)n + 1) * sizeof(TriIsect)));      // one spare record behind the last triangle
+    BUILD_TRY(hipMalloc(&out.shade, (size_t)n * sizeof(TriShade)));
+    BUILD_TRY(hipMalloc(&out.origin, (size_t)n * sizeof(TriOrigin)));
+    BUILD_TRY(hipMemsetAsync((TriIsect*)out.isect + n, 0, sizeof(TriIsect), nullptr));
+
+    // ---- 1, 2: Morton codes, sorted ----
+    uint32_t* d_bounds = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
+    uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr;
+    BUILD_TRY(tmp.get(&d_bounds, 6 * (size_t)n_objects));
+    BUILD_TRY(tmp.get(&d_keys, n));
+    BUILD_TRY(tmp.get(&d_keys_sorted, n));
+    BUILD_TRY(tmp.get(&d_ids, n));
+    BUILD_TRY(tmp.get(&d_ids_sorted, n));
+    std::vector<uint32_t> bounds_init(6 * (size_t)n_objects);
+    for (int i = 0; i < n_objects; i++)
+        for (int a = 0; a < 3; a++) { bounds_init[6 * i + a] = 0xFFFFFFFFu; bounds_init[6 * i + 3 + a] = 0u; }
+    BUILD_TRY(hipMemcpy(d_bounds, bounds_init.data(), bounds_init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    int object_bits = 0;
+    while ((1ll << object_bits) < n_objects) object_bits++;
+    const int axis_bits = std::min(21, (63 - object_bits) / 3);
+    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(blocks_for(n)), dim3(BUILD_BLOCK), 0, nullptr, d_tris, n, d_first, n_objects, d_bounds);
+    hipLaunchKernelGGL(morton_kernel, dim3(blocks_for(n)), dim3(BUILD_BLOCK), 0, nullptr, d_tris, n, d_first, n_objects, d_bounds, axis_bits, d_keys, d_ids);
+    BUILD_TRY(hipGetLastError());
+    {
+        size_t bytes = 0;
+        BUILD_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, (size_t)n, 0, 63, nullptr));
+        char* d_temp = nullptr;
+        BUILD_TRY(tmp.get(&d_temp, bytes));
+        BUILD_TRY(rocprim::radix_sort_pairs(d_temp, bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, (size_t)n, 0, 63, nullptr));
+    }
+    hipLaunchKernelGGL(emit_triangles_kernel, dim3(blocks_for(n)), dim3(BUILD_BLOCK), 0, nullptr, d_tris, d_ids_sorted, n, d_first, n_objects,
+                       (TriIsect*)out.isect, (TriShade*)out.shade, (TriOrigin*)out.origin);
+    BUILD_TRY(hipGetLastError());
+
+    // ---- 3, 4: leaves, hierarchy, boxes ----
+    Binary b = {};
+    uint64_t* d_leaf_keys = nullptr;
+    BUILD_TRY(tmp.get(&d_leaf_keys, m));
+    BUILD_TRY(tmp.get(&b.child, 2 * (size_t)inner));
+    BUILD_TRY(tmp.get(&b.parent, inner));
+    BUILD_TRY(tmp.get(&b.leaf_parent, m));
+    BUILD_TRY(tmp.get(&b.box, 6 * (size_t)inner));
+    BUILD_TRY(tmp.get(&b.leaf_box, 6 * (size_t)m));
+    BUILD_TRY(tmp.get(&b.arrived, inner));
+    BUILD_TRY(tmp.get(&b.depth, inner));
+    BUILD_TRY(hipMemsetAsync(b.arrived, 0, std::max<size_t>(inner, 1) * sizeof(uint32_t), nullptr));
+    hipLaunchKernelGGL(leaf_keys_kernel, dim3(blocks_for(m)), dim3(BUILD_BLOCK), 0, nullptr, d_keys_sorted, m, d_leaf_keys);
+    if (inner) hipLaunchKernelGGL(hierarchy_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, d_leaf_keys, (int)m, b);
+    hipLaunchKernelGGL(fit_kernel, dim3(blocks_for(m)), dim3(BUILD_BLOCK), 0, nullptr, d_tris, d_ids_sorted, n, m, b);
+    BUILD_TRY(hipGetLastError());
+
+    uint32_t n4 = 0, stack_need = 0, max_depth = 0;
+    float root_box[6];
+    uint32_t root_ref;
+    if (inner == 0) {
+        // one leaf: the scene root refers to it directly, there are no records
+        BUILD_TRY(hipMalloc(&out.nodes4, sizeof(Node4)));
+        BUILD_TRY(hipMemsetAsync(out.nodes4, 0, sizeof(Node4), nullptr));
+        BUILD_TRY(hipMemcpy(root_box, b.leaf_box, sizeof root_box, hipMemcpyDeviceToHost));
+        root_ref = REF_LEAF | 0u | (n > 1 ? REF_PAIR : 0u);
+    } else {
+        // ---- 5: even-depth inner nodes -> records, numbered by (level, falling area) ----
+        uint32_t *d_even = nullptr, *d_even_pos = nullptr, *d_max_depth = nullptr;
+        BUILD_TRY(tmp.get(&d_even, (size_t)inner + 1));
+        BUILD_TRY(tmp.get(&d_even_pos, (size_t)inner + 1));
+        BUILD_TRY(tmp.get(&d_max_depth, 1));
+        BUILD_TRY(hipMemsetAsync(d_max_depth, 0, sizeof(uint32_t), nullptr));
+        BUILD_TRY(hipMemsetAsync(d_even + inner, 0, sizeof(uint32_t), nullptr));
+        hipLaunchKernelGGL(depth_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_even, d_max_depth);
+        BUILD_TRY(hipGetLastError());
+        {
+            size_t bytes = 0;
+            BUILD_TRY(rocprim::exclusive_scan(nullptr, bytes, d_even, d_even_pos, 0u, (size_t)inner + 1, rocprim::plus<uint32_t>(), nullptr));
+            char* d_temp = nullptr;
+            BUILD_TRY(tmp.get(&d_temp, bytes));
+            BUILD_TRY(rocprim::exclusive_scan(d_temp, bytes, d_even, d_even_pos, 0u, (size_t)inner + 1, rocprim::plus<uint32_t>(), nullptr));
+        }
+        BUILD_TRY(hipMemcpy(&n4, d_even_pos + inner, sizeof n4, hipMemcpyDeviceToHost));
+        BUILD_TRY(hipMemcpy(&max_depth, d_max_depth, sizeof max_depth, hipMemcpyDeviceToHost));
+        uint64_t *d_k4 = nullptr, *d_k4_sorted = nullptr;
+        uint32_t *d_n4 = nullptr, *d_n4_sorted = nullptr, *d_rank = nullptr;
+        BUILD_TRY(tmp.get(&d_k4, n4));
+        BUILD_TRY(tmp.get(&d_k4_sorted, n4));
+        BUILD_TRY(tmp.get(&d_n4, n4));
+        BUILD_TRY(tmp.get(&d_n4_sorted, n4));
+        BUILD_TRY(tmp.get(&d_rank, inner));
+        hipLaunchKernelGGL(even_keys_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_even, d_even_pos, d_k4, d_n4);
+        BUILD_TRY(hipGetLastError());
+        {
+            size_t bytes = 0;
+            BUILD_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 40, nullptr));
+            char* d_temp = nullptr;
+            BUILD_TRY(tmp.get(&d_temp, bytes));
+            BUILD_TRY(rocprim::radix_sort_pairs(d_temp, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 40, nullptr));
+        }
+        hipLaunchKernelGGL(rank_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, d_n4_sorted, d_rank);
+        // ---- 6: records, slot order, stack need ----
+        Records rec = {};
+        BUILD_TRY(hipMalloc(&out.nodes4, (size_t)n4 * sizeof(Node4)));
+        rec.nodes4 = (Node4*)out.nodes4;
+        BUILD_TRY(tmp.get(&rec.parent4, n4));
+        BUILD_TRY(tmp.get(&rec.inner_slots, n4));
+        BUILD_TRY(tmp.get(&rec.arrived4, n4));
+        BUILD_TRY(tmp.get(&rec.need4, n4));
+        BUILD_TRY(hipMemsetAsync(rec.arrived4, 0, (size_t)n4 * sizeof(uint32_t), nullptr));
+        const char* order_env = std::getenv("RT_BUILD_ORDER");
+        const int order = order_env ? std::atoi(order_env) : 0;        // experiment switch: 0 = deepest last, 1 = lower codes first, 2 = higher codes first
+        hipLaunchKernelGGL(emit_records_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, n, d_n4_sorted, d_rank, b, rec, order == 2 ? 1 : 0);
+        hipLaunchKernelGGL(need_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, rec, order == 0 ? 1 : 0);
+        BUILD_TRY(hipGetLastError());
+        BUILD_TRY(hipMemcpy(&stack_need, rec.need4, sizeof stack_need, hipMemcpyDeviceToHost));      // record 0 is the root
+        BUILD_TRY(hipMemcpy(root_box, b.box, sizeof root_box, hipMemcpyDeviceToHost));               // inner node 0 is the root
+        root_ref = 0u;
+    }
+    uint32_t* d_last = nullptr;
+    BUILD_TRY(tmp.get(&d_last, 1));
+    hipLaunchKernelGGL(last_triangle_kernel, dim3(1), dim3(1), 0, nullptr, (const Node4*)out.nodes4, root_ref, d_last);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipEventRecord(ev[2], nullptr));
+    BUILD_TRY(hipMemcpy(&out.last_tri, d_last, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    BUILD_TRY(hipDeviceSynchronize());
+    float ms_copy = 0.0f, ms_build = 0.0f;
+    (void)hipEventElapsedTime(&ms_copy, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&ms_build, ev[1], ev[2]);
+    for (int a = 0; a < 3; a++) { out.root.bmin[a] = root_box[a]; out.root.bmax[a] = root_box[3 + a]; }
+    out.root.ref = root_ref;
+    out.root.aux = 0;
+    out.n_triangles = n;
+    out.n_nodes4 = n4;
+    out.stack_need = (int)stack_need;
+    out.binary_depth = (int)max_depth + 1;
+    out.bytes = ((size_t)n + 1) * sizeof(TriIsect) + (size_t)n * (sizeof(TriShade) + sizeof(TriOrigin)) + std::max<size_t>(n4, 1) * sizeof(Node4);
+    out.copy_ms = ms_copy;
+    out.build_ms = ms_build;
+    return 0;
+}
+
+}  // namespace rtc

@@ -311,8 +311,8 @@ struct Walker {
             tc.ray_visits++;
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_leaf++;
         }
-        // both records are fetched at once (one memory round trip per leaf visit, not two); the array ends with a spare record
-        // lanes at a one-triangle leaf do not read the second record: every 16-byte piece a lane reads is an L1 access
+        // both records of a two-triangle leaf are fetched at once (one memory round trip per leaf visit, not two); lanes at
+        // a one-triangle leaf do not read a second record: every 16-byte piece a lane reads is an L1 access
         const float4* q = reinterpret_cast<const float4*>(sc.isect + p);
         const bool pair = (cur & REF_PAIR) != 0;
         const float4 a0 = q[0], a1 = q[1], a2 = q[2];

@@ -263,6 +263,9 @@ CameraFrame camera_frame(int width, int height, const float pos[3], const float 
     const V3 right = crs(dir, up);
     up = crs(right, dir);
     const float aspect = (float)width / (float)height;
+    // upstream writes an unqualified tan(fov / 2.0f) in a .cu file (cuda/camera.cu:55); with a float argument both
+    // overload sets it can resolve to (CUDA's and <cmath>'s) give the binary32 function, so tanf it is.  Its last bit is
+    // the host math library's; the oracle calls the same function.
     const float hh = tanf(fov / 2.0f);
     const float hw = aspect * hh;
     CameraFrame f;
@@ -546,6 +549,8 @@ static void renumber_breadth_first(PackedScene& ps) {
     ps.root.ref = 0;
 }
 
+// A median-split tree over 2^30 triangles has 30 levels; the walk's stack (LDS + private spill) takes about 60.
+#define RT_MAX_TREE_LEVELS 512
 int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::string& err) {
     ps = PackedScene();
     for (int i = 0; i < n_objects; i++) {
@@ -564,6 +569,7 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
         std::vector<uint32_t>& tri = tris_below[i];
         inner.resize(o.n_bvh_nodes);
         tri.resize(o.n_bvh_nodes);
+        std::vector<uint16_t> levels(o.n_bvh_nodes);     // the emission below recurses once per level: a chain-shaped tree must not reach it
         for (int k = 0; k < o.n_bvh_nodes; k++) {
             const rt_bvh_node& n = o.bvh[k];
             const int lim = n.is_leaf ? o.n_triangles : o.n_bvh_nodes;
@@ -574,7 +580,13 @@ int pack_scene(const rt_object* objects, int n_objects, PackedScene& ps, std::st
             if (n.is_leaf) {
                 inner[k] = 0;
                 tri[k] = n.right >= 0 ? 2 : 1;
+                levels[k] = 1;
             } else {
+                levels[k] = uint16_t(1 + std::max(levels[n.left], levels[n.right]));
+                if (levels[k] > RT_MAX_TREE_LEVELS) {
+                    err = "object " + std::to_string(i) + ": BVH deeper than " + std::to_string(RT_MAX_TREE_LEVELS) + " levels";
+                    return -1;
+                }
                 const uint64_t a = uint64_t(inner[n.left]) + inner[n.right] + 1, b = uint64_t(tri[n.left]) + tri[n.right];
                 if (a > REF_MASK || b > REF_MASK) { err = "scene exceeds 2^30-1 triangles"; return -1; }
                 inner[k] = uint32_t(a);

@@ -1,22 +1,21 @@
 // rt_kernels.hip -- gfx950 kernels of the path-tracing core and the C ABI around them.
 //
 // Kernel design (wave64, 256 CUs, no MFMA: nothing here is a dense contraction):
-//  * one lane owns one pixel and walks that pixel's samples in order, as a flat
-//    state machine: every trip of the main loop traces ONE ray segment for every
-//    live lane, whatever sample/bounce that lane is on, so a lane whose path
-//    ended starts its next sample at once instead of idling until the slowest
-//    path of the wave ends (upstream's nested spp/depth loops,
-//    cuda/raytrace.cu:209-245, reconverge at every sample);
-//  * a wave covers an 8x8 pixel tile, a 256-thread workgroup a 16x16 tile, and
-//    workgroups are dealt so that each XCD's L2 serves one band of the image;
-//  * traversal visits nodes in upstream's order (objects ascending, right child
-//    first, leaf left triangle then right, prune on t_near > best t), which
-//    makes hit records bit-identical, but it reads one 64-byte record per inner
-//    node that holds both children's boxes, hoists 1/dir out of the slab test,
-//    keeps its stack in LDS (one 8-byte column per lane, conflict-free) and
-//    lets every lane advance through the object list on its own;
-//  * random numbers are Philox4x32-10 keyed by (seed; pixel, sample, block,
-//    stream): no state array, results independent of launch batching.
+//  * Two schedules of the same paths, bit-identical in their results.  Wavefront (default): path state lives in HBM
+//    pools and every iteration runs one kernel per stage -- wf_shade_kernel (consume hits, scatter, compact survivors
+//    with 64-bit ballots), wf_plan_kernel + wf_generate_kernel (refill with new camera paths in tile order) and
+//    wf_extend_kernel (closest hit).  Megakernel: path_kernel, one lane tracing a chunk of samples of one pixel as a
+//    flat state machine.  Either way every finished path writes its radiance to a slot per (sample, pixel), and
+//    accumulate_kernel sums the slots in upstream's order (cuda/raytrace.cu:208-246, csrc/worker.cpp:71-91).
+//  * wf_extend_kernel fills the chip once per launch (768-lane workgroups, two per CU); waves claim chunks of 256 pool
+//    entries from one queue per XCD, lanes take the next ray of the chunk as soon as theirs ends, and each trip the
+//    wave runs the visit kind (node or leaf) most of its lanes wait for.
+//  * The walk visits nodes in upstream's order (objects ascending, right child first, leaf left triangle then right,
+//    prune on t_near > best t), which makes hit records bit-identical; it reads one 128-byte two-level record per
+//    visit (the boxes of up to four grandchildren, rt_packed.h), hoists 1/dir out of the slab test, keeps the first
+//    stack levels in LDS (one 8-byte column per lane, conflict-free) and the most-entered node records in LDS too.
+//  * Random numbers are Philox4x32-10 with addressed draws (pixel, sample, slot, stream): no state array, results
+//    independent of launch batching, kernel design and GPU count.
 //
 // Built with -ffp-contract=off; expressions keep upstream's operand order.
 #include <hip/hip_runtime.h>
@@ -27,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_build.h"
 #include "rt_device.h"
 
 __device__ __forceinline__ void add_trav_counters(unsigned long long* counters, const TravCounters& tc) {
@@ -209,8 +209,9 @@ __global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, ui
     if (threadIdx.x || blockIdx.x) return;
     if (ctl->n_worked) {
         // fold the previous closest-hit launch's wave times: slot-ticks the launch spanned, and those left idle behind waves that ended early
-        counters[RT_CNT_LAUNCH_SLOT_TICKS] += (ctl->t_last - ctl->t_first) * ctl->n_worked;
-        counters[RT_CNT_TAIL_IDLE_TICKS] += ctl->t_last * ctl->n_worked - ctl->t_end_sum;
+        // (atomic: with two pipelines per pass, two planners may run at once)
+        atomicAdd(&counters[RT_CNT_LAUNCH_SLOT_TICKS], (ctl->t_last - ctl->t_first) * ctl->n_worked);
+        atomicAdd(&counters[RT_CNT_TAIL_IDLE_TICKS], ctl->t_last * ctl->n_worked - ctl->t_end_sum);
     }
     ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
     const uint32_t have = ctl->count[nxt];
@@ -695,6 +696,7 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
+    int opt_gpu_bvh = 0;             // 1 = rt_upload_scene builds its own tree on the device instead of re-packing the caller's
     int opt_lds_slots = 11;          // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
     int opt_pass = 1024;             // samples per pixel held in the slot buffer at once (less when that would exceed RT_SLOTS_MAX_BYTES)
@@ -851,6 +853,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_COUNTERS: ctx->opt_counters = value ? 1 : 0; return RT_OK;
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
     case RT_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return RT_OK;
+    case RT_OPT_GPU_BVH: ctx->opt_gpu_bvh = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
@@ -909,10 +912,6 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     for (int i = 0; i < n_textures; i++)
         if (!textures[i].rgba || textures[i].width <= 0 || textures[i].height <= 0) return fail(RT_ERR_INVALID, "rt_upload_scene: empty texture");
 
-    PackedScene ps;
-    std::string err;
-    if (pack_scene(objects, n_objects, ps, err) != 0) return fail(RT_ERR_INVALID, "rt_upload_scene: " + err);
-
     std::vector<MatDev> mats(n_materials);
     for (int i = 0; i < n_materials; i++) {
         mats[i].type = materials[i].type;
@@ -934,20 +933,48 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     }
 
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
-    free_scene(ctx);
     uint64_t bytes = 0;
     int rc;
-    if ((rc = upload_vec(ps.nodes4, &ctx->d_nodes, bytes))) return rc;
-    const size_t n_packed_tris = ps.isect.size();
-    ps.isect.push_back(TriIsect{});          // one spare record: a leaf visit always fetches two records, the second one unused for a single-triangle leaf
-    if ((rc = upload_vec(ps.isect, &ctx->d_isect, bytes))) return rc;
-    if ((rc = upload_vec(ps.shade, &ctx->d_shade, bytes))) return rc;
-    if ((rc = upload_vec(ps.origin, &ctx->d_origin, bytes))) return rc;
+    std::string err;
+    if (ctx->opt_gpu_bvh) {
+        // the tree is built on the device from the triangles alone (rt_build.hip); the callers' node arrays are not read
+        HIP_TRY(hipDeviceSynchronize());
+        free_scene(ctx);
+        DeviceScene ds;
+        if (build_scene_on_device(objects, n_objects, ds, err) != 0) return fail(RT_ERR_DEVICE, "rt_upload_scene: device build: " + err);
+        ctx->d_nodes = ds.nodes4; ctx->d_isect = ds.isect; ctx->d_shade = ds.shade; ctx->d_origin = ds.origin;
+        ctx->dev.root = ds.root;
+        ctx->dev.last_tri = ds.last_tri;
+        ctx->stack_slots = ds.stack_need > 0 ? ds.stack_need : 1;
+        ctx->stats[0] = ds.n_triangles;
+        ctx->stats[1] = ds.n_nodes4;
+        ctx->stats[5] = (uint64_t)(ds.build_ms * 1000.0f);
+        ctx->stats[6] = (uint64_t)(ds.copy_ms * 1000.0f);
+        ctx->stats[7] = (uint64_t)ds.binary_depth;
+        bytes = ds.bytes;
+    } else {
+        for (int i = 0; i < n_objects; i++)
+            if (!objects[i].bvh || objects[i].n_bvh_nodes <= 0) return fail(RT_ERR_INVALID, "rt_upload_scene: object without a node array (set RT_OPT_GPU_BVH to have the tree built on the device)");
+        PackedScene ps;
+        if (pack_scene(objects, n_objects, ps, err) != 0) return fail(RT_ERR_INVALID, "rt_upload_scene: " + err);
+        HIP_TRY(hipDeviceSynchronize());
+        free_scene(ctx);
+        if ((rc = upload_vec(ps.nodes4, &ctx->d_nodes, bytes))) return rc;
+        const size_t n_packed_tris = ps.isect.size();
+        ps.isect.push_back(TriIsect{});          // one spare record behind the last triangle: no kernel reads it, it only keeps a fetch that runs past a final one-triangle leaf inside the allocation
+        if ((rc = upload_vec(ps.isect, &ctx->d_isect, bytes))) return rc;
+        if ((rc = upload_vec(ps.shade, &ctx->d_shade, bytes))) return rc;
+        if ((rc = upload_vec(ps.origin, &ctx->d_origin, bytes))) return rc;
+        ctx->dev.root = ps.root;
+        ctx->dev.last_tri = ps.last_tri;
+        ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
+        ctx->stats[0] = n_packed_tris;
+        ctx->stats[1] = ps.nodes4.size();
+        ctx->stats[5] = ctx->stats[6] = ctx->stats[7] = 0;
+    }
     if ((rc = upload_vec(mats, &ctx->d_mats, bytes))) return rc;
     if ((rc = upload_vec(tex, &ctx->d_tex, bytes))) return rc;
     if ((rc = upload_vec(texels, &ctx->d_texels, bytes))) return rc;
-    ctx->dev.root = ps.root;
     ctx->dev.nodes = (const Node4*)ctx->d_nodes;
     ctx->dev.isect = (const TriIsect*)ctx->d_isect;
     ctx->dev.shade = (const TriShade*)ctx->d_shade;
@@ -956,10 +983,6 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->dev.tex = (const TexDev*)ctx->d_tex;
     ctx->dev.texels = (const uint32_t*)ctx->d_texels;
     ctx->dev.n_materials = n_materials;
-    ctx->dev.last_tri = ps.last_tri;
-    ctx->stack_slots = ps.max_depth > 0 ? ps.max_depth : 1;
-    ctx->stats[0] = n_packed_tris;
-    ctx->stats[1] = ps.nodes4.size();
     ctx->stats[2] = (uint64_t)ctx->stack_slots;
     ctx->stats[3] = bytes;
     ctx->stats[4] = (uint64_t)n_objects;
@@ -1034,25 +1057,34 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     while (cap > (1u << 16) && (unsigned long long)(cap >> 1) >= pass_paths) cap >>= 1;
     if (ctx->pool_capacity < cap || ctx->lanes_allocated < n_lanes) {
         HIP_TRY(hipStreamSynchronize(s));
-        free_pools(ctx);
-        HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-        for (int l = 0; l < n_lanes; l++) {
-            rt_context::WfLane& L = ctx->lanes[l];
-            for (int k = 0; k < 2; k++) {
-                HIP_TRY(hipMalloc((void**)&L.pools.p0[k], (size_t)cap * sizeof(float4)));
-                HIP_TRY(hipMalloc((void**)&L.pools.p1[k], (size_t)cap * sizeof(float4)));
-                HIP_TRY(hipMalloc((void**)&L.pools.p2[k], (size_t)cap * sizeof(float4)));
+        // a device with less free memory than the default pool takes (15 GB) gets a smaller pool, not an error
+        for (;;) {
+            free_pools(ctx);
+            hipError_t e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+            for (int l = 0; l < n_lanes && e == hipSuccess; l++) {
+                rt_context::WfLane& L = ctx->lanes[l];
+                for (int k = 0; k < 2 && e == hipSuccess; k++) {
+                    e = hipMalloc((void**)&L.pools.p0[k], (size_t)cap * sizeof(float4));
+                    if (e == hipSuccess) e = hipMalloc((void**)&L.pools.p1[k], (size_t)cap * sizeof(float4));
+                    if (e == hipSuccess) e = hipMalloc((void**)&L.pools.p2[k], (size_t)cap * sizeof(float4));
+                }
+                if (e == hipSuccess) e = hipMalloc((void**)&L.pools.hit, (size_t)cap * sizeof(float4));
+                if (e == hipSuccess) e = hipMalloc((void**)&L.d_ctl, sizeof(WfCtl));
+                if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_ctl, RT_CTL_RING * sizeof(WfCtl), hipHostMallocDefault);
+                for (int k = 0; k < RT_CTL_RING && e == hipSuccess; k++) e = hipEventCreateWithFlags(&L.ctl_ev[k], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&L.done, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
             }
-            HIP_TRY(hipMalloc((void**)&L.pools.hit, (size_t)cap * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&L.d_ctl, sizeof(WfCtl)));
-            HIP_TRY(hipHostMalloc((void**)&L.h_ctl, RT_CTL_RING * sizeof(WfCtl), hipHostMallocDefault));
-            for (int k = 0; k < RT_CTL_RING; k++) HIP_TRY(hipEventCreateWithFlags(&L.ctl_ev[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
-            HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            free_pools(ctx);
+            if (e != hipErrorOutOfMemory || cap <= (1u << 16)) return fail(RT_ERR_DEVICE, std::string("rt_raytrace: path pools: ") + hipGetErrorString(e));
+            cap >>= 1;
         }
         ctx->lanes_allocated = n_lanes;
         ctx->pool_capacity = cap;
     }
+    cap = std::min(cap, ctx->pool_capacity);     // what this pass uses of them (less than asked for if memory was short)
     const int slots_lds = lds_slots(ctx);
     const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
     const uint32_t eb = (uint32_t)ctx->opt_wf_block;

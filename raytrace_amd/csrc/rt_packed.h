@@ -1,13 +1,13 @@
 // rt_packed.h -- device-side scene layout, shared by the host re-packer and the kernels.
 //
-// Upstream keeps one 36-byte BVHNode array and one 104-byte Triangle array per
-// OBJ shape (include/bvh.h:62-65, include/primitives.cuh:28-31) and fetches a
-// node, tests its own box, then fetches children.  Here every inner node is one
-// 64-byte, 64-byte-aligned record that carries BOTH children's boxes, so one
-// cache-line fetch decides both children and leaves need no node record at all.
-// Triangles are split into a 48-byte intersection record (v0, e1, e2) stored in
-// leaf order (a leaf's two triangles are adjacent) and a 64-byte shading record
-// read once per hit.
+// Upstream keeps one 36-byte BVHNode array and one 104-byte Triangle array per OBJ shape (include/bvh.h:62-65,
+// include/primitives.cuh:28-31) and fetches a node, tests its own box, then fetches children.  Here all objects hang
+// under one tree, and what the kernels walk are 128-byte, 128-byte-aligned two-level records (Node4): the boxes of the
+// up to four grandchildren of a binary node in visiting order, then their references -- one cache line decides two
+// tree levels, and leaves need no node record at all (a leaf is a reference).  The 64-byte binary records (Node64)
+// exist only while the packer builds the tree.  Triangles are split into a 48-byte intersection record (v0, e1, e2)
+// stored in leaf order (a leaf's two triangles are adjacent, and the order of the array is upstream's visiting order)
+// and a 64-byte shading record read once per hit.
 #ifndef RT_PACKED_H
 #define RT_PACKED_H
 
@@ -15,7 +15,7 @@
 
 namespace rtc {
 
-// Reference to a child: inner -> index into the Node64 array; leaf -> packed
+// Reference to a child: inner -> index into the node array (Node4 for the kernels); leaf -> packed
 // triangle index of the leaf's first triangle, with flags.
 constexpr uint32_t REF_LEAF = 0x80000000u;   // child is a leaf
 constexpr uint32_t REF_PAIR = 0x40000000u;   // leaf holds two triangles (p and p+1)

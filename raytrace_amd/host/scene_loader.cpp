@@ -338,6 +338,13 @@ int SceneLoader::load_scene(const std::string& filename) {
         }
     }
     parsed_.clear();                                              // the parsed model files are not needed any more
+    // RT_GPU_BVH=1: no trees are built here; upload() asks the library to build one on the device (RT_OPT_GPU_BVH)
+    const char* on_device = std::getenv("RT_GPU_BVH");
+    device_tree_ = on_device && std::atoi(on_device) != 0;
+    if (device_tree_) {
+        std::cout << "\nBVH tree: left to the device" << std::endl;
+        return 0;
+    }
     std::cout << "\nBuilding BVH tree... ";
     for (HostObject& o : objects_) {
         o.bvh.resize(2 * o.triangles.size());
@@ -357,9 +364,9 @@ int SceneLoader::upload(rt_context* ctx) const {
     std::vector<rt_object> objs(objects_.size());
     for (size_t i = 0; i < objects_.size(); i++) {
         objs[i].triangles = objects_[i].triangles.data();
-        objs[i].bvh = objects_[i].bvh.data();
+        objs[i].bvh = device_tree_ ? nullptr : objects_[i].bvh.data();
         objs[i].n_triangles = int(objects_[i].triangles.size());
-        objs[i].n_bvh_nodes = int(objects_[i].bvh.size());
+        objs[i].n_bvh_nodes = device_tree_ ? 0 : int(objects_[i].bvh.size());
     }
     std::vector<rt_texture> texs(textures_.size());
     for (size_t i = 0; i < textures_.size(); i++) {
@@ -367,6 +374,7 @@ int SceneLoader::upload(rt_context* ctx) const {
         texs[i].width = textures_[i].width;
         texs[i].height = textures_[i].height;
     }
+    if (device_tree_ && rt_set_option(ctx, RT_OPT_GPU_BVH, 1) != RT_OK) return RT_ERR_INVALID;
     return rt_upload_scene(ctx, objs.data(), int(objs.size()), materials_.data(), int(materials_.size()), texs.data(), int(texs.size()));
 }
 

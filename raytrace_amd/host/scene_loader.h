@@ -52,6 +52,7 @@ class SceneLoader {
     std::vector<rt_material> materials_;
     std::vector<HostTexture> textures_;
     RenderConfig config_;
+    bool device_tree_ = false;       // RT_GPU_BVH=1: the scene tree is built on the device at upload
     // model files already read during this load_scene, by path and MTL directory: a scene that places one model many
     // times (upstream reads the file again for every object block) reads it once
     std::map<std::string, std::shared_ptr<ObjModel>> parsed_;

@@ -1,0 +1,157 @@
+"""The scene tree built on the GPU (RT_OPT_GPU_BVH): a different tree than upstream's, so its hit records are checked
+against an exhaustive search over all triangles (the oracle's brute-force nearest t), not against upstream's walk.
+
+What may differ from the exhaustive search, and does in well under 1 % of rays: a box whose slab test rejects a ray that
+the Moller-Trumbore test of a triangle inside would accept (both tests are upstream's arithmetic; they disagree for rays
+that graze a box face or a triangle edge).  Such a ray's hit is then a farther triangle or a miss -- never a nearer one,
+and never a t that no triangle gives.  Upstream's own walk has the same property on its own boxes."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from raytrace_amd import capi, scene
+from tests.util import bits, random_rays, same_f32
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED0001
+
+
+def _hits(ctx, rays):
+    import torch
+    n = len(rays)
+    d_rays = torch.from_numpy(np.ascontiguousarray(rays, dtype=np.float32)).cuda()
+    d_obj = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    d_tri = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    d_t, d_u, d_v = (torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    torch.cuda.synchronize()
+    ctx.closest_hit(n, d_rays.data_ptr(), d_obj.data_ptr(), d_tri.data_ptr(), d_t.data_ptr(), d_u.data_ptr(), d_v.data_ptr())
+    ctx.synchronize()
+    return d_obj.cpu().numpy(), d_tri.cpu().numpy(), d_t.cpu().numpy(), d_u.cpu().numpy(), d_v.cpu().numpy()
+
+
+def _two_contexts(asm):
+    """The same scene twice: upstream's trees re-packed (default) and the tree built on the device."""
+    cfg = asm.config
+    objs = scene.finalize(asm)
+    ref = capi.Context(0)
+    ref.upload_scene(objs, asm.materials, asm.textures)
+    own = capi.Context(0)
+    own.set_option(capi.OPT_GPU_BVH, 1)
+    own.upload_scene([(t, None) for t, _ in objs], asm.materials, asm.textures)        # no node arrays at all
+    for c in (ref, own):
+        c.init_randstate(SEED, cfg.width, cfg.height)
+        c.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+    return objs, ref, own
+
+
+@pytest.mark.parametrize("name,kw,box", [
+    ("material_box", dict(width=96, height=64, n_samples=4), 6.0),
+    ("formula1", dict(width=200, height=120, n_samples=4, detail=0.15, tex_size=64), 150.0),
+    ("luyu", dict(width=200, height=120, n_samples=4, statue_tris=60000), 200.0),
+])
+def test_device_built_tree_agrees_with_exhaustive_search(name, kw, box):
+    asm = getattr(scene, name)(**kw)
+    objs, ref, own = _two_contexts(asm)
+    try:
+        st = own.scene_stats()
+        assert st["triangles"] == sum(len(t) for t, _ in objs) and 0 < st["stack_slots"] <= 60
+        oracle = orc.Scene(objs, asm.materials, asm.textures)
+        rays = np.concatenate([orc.primary_rays(orc.make_params(asm.config, SEED, 4), 0)[::3],
+                               random_rays(np.random.RandomState(11), 20000, -box, box)])
+        brute = oracle.closest_hit_brute(rays)
+        o, tr, t, u, v = _hits(own, rays)
+        ro, rtr, rt, ru, rv = _hits(ref, rays)
+        finite = np.isfinite(rays).all(axis=1)
+        # never nearer than the exhaustive search, never a t no triangle gives
+        assert (t[finite] >= brute[finite]).all()
+        same = bits(t) == bits(brute)
+        missed = ~same & finite
+        print(f"{name}: {missed.sum()} of {len(rays)} rays differ from the exhaustive search (slab test rejects a box whose triangle test accepts); "
+              f"upstream's tree: {(bits(rt) != bits(brute)).sum()}")
+        assert same.mean() > 0.995
+        assert ((o >= 0) == np.isfinite(t)).all() and (u[o >= 0] >= 0).all() and (v[o >= 0] >= 0).all() and ((u + v)[o >= 0] <= 1).all()
+        # where both trees see the same t, they name the same triangle except at exact ties (shared edges), where the
+        # last triangle visited wins and the visiting orders differ
+        both = bits(t) == bits(rt)
+        assert both.mean() > 0.995
+        ties = both & ((o != ro) | (tr != rtr))
+        print(f"{name}: {ties.sum()} exact ties resolved differently")
+        assert ties.mean() < 0.02
+        assert same_f32(u[both & ~ties], ru[both & ~ties])
+    finally:
+        ref.close()
+        own.close()
+
+
+def test_device_built_tree_renders_the_same_picture_up_to_tie_rays():
+    import torch
+    asm = scene.formula1(width=160, height=96, n_samples=16, detail=0.1, tex_size=64)
+    cfg = asm.config
+    _, ref, own = _two_contexts(asm)
+    try:
+        npix = cfg.width * cfg.height
+        out = []
+        for c in (ref, own):
+            d = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            c.raytrace(npix, 0, 16, 4, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+            c.synchronize()
+            out.append(d.cpu().numpy())
+        a, b = out
+        identical = (bits(a) == bits(b)).all(axis=1).mean()
+        print(f"{identical:.4f} of the pixels bit-identical between the two trees")
+        assert identical > 0.9                       # same seed, same draws: paths differ only where a tie or a grazing ray falls
+        assert abs(float(a.mean()) - float(b.mean())) < 0.02 * float(a.mean())
+    finally:
+        ref.close()
+        own.close()
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5])
+def test_device_built_tree_of_a_few_triangles(n_tris):
+    """One leaf (no records at all), one record with two leaves, odd counts: the edge shapes of the hierarchy."""
+    tris = np.zeros(n_tris, dtype=capi.TRIANGLE_DTYPE)
+    for k in range(n_tris):
+        tris["v"]["position"][k] = [[0, 0, k], [1, 0, k], [0, 1, k]]
+        tris["v"]["normal"][k] = [[0, 0, 1]] * 3
+    mats = np.zeros(1, dtype=capi.MATERIAL_DTYPE)
+    mats["type"] = capi.MAT_LAMBERTIAN
+    mats["texture"] = -1
+    ctx = capi.Context(0)
+    try:
+        ctx.set_option(capi.OPT_GPU_BVH, 1)
+        ctx.upload_scene([(tris, None)], mats, [])
+        rays = np.array([[0.25, 0.25, 10, 0, 0, -1], [0.25, 0.25, -10, 0, 0, 1], [5, 5, 10, 0, 0, -1], [0.25, 0.25, 1.5, 0, 0, -1]], dtype=np.float32)
+        o, tr, t, u, v = _hits(ctx, rays)
+        assert list(tr[:3]) == [n_tris - 1, 0, -1] and list(o[:3]) == [0, 0, -1]
+        assert t[0] == 10 - (n_tris - 1) and t[1] == 10 and np.isinf(t[2])
+        assert tr[3] == (1 if n_tris > 1 else 0) and u[0] == 0.25 and v[0] == 0.25
+    finally:
+        ctx.close()
+
+
+def test_device_build_of_the_30m_triangle_scene_is_fast_and_agrees_with_upstreams_walk():
+    asm = scene.stress(width=960, height=540, n_samples=1)
+    cfg = asm.config
+    objs, ref, own = _two_contexts(asm)
+    try:
+        st = own.scene_stats()
+        print(f"30 M triangles: device build {st['gpu_build_ms']:.1f} ms, copy of the triangle arrays {st['gpu_copy_ms']:.1f} ms, "
+              f"{st['inner_nodes']} records, stack need {st['stack_slots']}, binary levels {st['gpu_binary_levels']}")
+        assert st["triangles"] > 30_000_000
+        assert st["gpu_build_ms"] < 500.0
+        import torch
+        d = torch.zeros(cfg.width * cfg.height, 6, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        own.primary_rays(0, d.data_ptr())
+        own.synchronize()
+        rays = d.cpu().numpy()
+        o, tr, t, u, v = _hits(own, rays)
+        ro, rtr, rt, ru, rv = _hits(ref, rays)
+        agree = bits(t) == bits(rt)
+        print(f"{(~agree).sum()} of {len(rays)} primary rays see another t than upstream's walk")
+        assert agree.mean() > 0.995 and (o >= 0).mean() > 0.5
+    finally:
+        ref.close()
+        own.close()

@@ -239,3 +239,19 @@ def test_bin_main_on_a_benchmark_scene_file(tmp_path):
     got = scene_files.read_png_rgb(str(out / "scene_formula1-output.png"))
     want = expected_png_pixels(asm, 4, SEED)
     assert np.array_equal(got, want), f"{(got != want).any(axis=2).sum()} pixels differ"
+
+
+def test_bin_main_with_the_tree_built_on_the_device(tmp_path):
+    """RT_GPU_BVH=1: the loader builds no trees, the library builds one on the device.  Same seed, same draws; the picture
+    is the default one except where a ray meets an exact tie or a grazing disagreement (another tree, another visiting
+    order), which this closed scene's shared edges do produce in a few pixels."""
+    asm = scene.material_box(width=64, height=40, n_samples=16)
+    path = scene_files.write_scene(asm, str(tmp_path / "files"), name="boxes")
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([MAIN, path, str(out), "4"], capture_output=True, text=True, timeout=120, env=dict(os.environ, RT_SEED=str(SEED), RT_GPU_BVH="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "BVH tree: left to the device" in r.stdout and "Image saved to" in r.stdout
+    got = scene_files.read_png_rgb(str(out / "boxes-output.png")).astype(int)
+    want = expected_png_pixels(asm, 4, SEED).astype(int)
+    assert (np.abs(got - want).max(axis=2) > 8).mean() < 0.05 and abs(got.mean() - want.mean()) < 1.0

@@ -329,6 +329,22 @@ def test_errors_are_reported(gpu_ctx):
     bad["texture"][0] = 5
     with pytest.raises(capi.RtError, match="texture index"):
         fresh.upload_scene(p.objs, bad, p.asm.textures)
+    # a chain-shaped tree (every inner node = the chain so far + one more leaf) handed in through the ABI: refused before
+    # the packer, which recurses once per level, walks it
+    n = 700
+    tris = np.zeros(n, dtype=capi.TRIANGLE_DTYPE)
+    tris["v"]["position"][:, 1, 0] = 1.0
+    tris["v"]["position"][:, 2, 1] = 1.0
+    tris["v"]["position"][:, :, 2] = np.arange(n, dtype=np.float32)[:, None]
+    nodes = np.zeros(2 * n - 1, dtype=capi.NODE_DTYPE)
+    nodes["box_min"], nodes["box_max"] = (0, 0, 0), (1, 1, n)
+    nodes[0]["is_leaf"], nodes[0]["left"], nodes[0]["right"] = 1, 0, -1
+    for k in range(1, n):
+        leaf, inner = 2 * k - 1, 2 * k
+        nodes[leaf]["is_leaf"], nodes[leaf]["left"], nodes[leaf]["right"] = 1, k, -1
+        nodes[inner]["is_leaf"], nodes[inner]["left"], nodes[inner]["right"] = 0, inner - 2 if k > 1 else 0, leaf
+    with pytest.raises(capi.RtError, match="deeper than"):
+        fresh.upload_scene([(tris, nodes)], p.asm.materials, p.asm.textures)
     fresh.close()
     assert lib.rt_last_error() != b""
 
