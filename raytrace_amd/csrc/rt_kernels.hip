@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -193,40 +194,91 @@ struct WfPools {
 
 #define RT_QUEUES 8u
 #define RT_QUEUE_STRIDE 32u
+// The pool is cut into `regions` equal parts (a power of two, at most RT_REGIONS_MAX, each a multiple of 256 entries).
+// A path stays in its region for life: the shading workgroups that read region r of one pool write their survivors to
+// the front of region r of the other, each wave taking its places with one returning atomic on that region's own
+// counter -- no counter is shared by workgroups that run at the same time (workgroup b reads region b mod regions), so
+// the compaction needs neither a barrier nor a chip-wide hot word -- and the refill tops every region up with a
+// contiguous run of new path ids.  The closest-hit launch sees the regions' live entries as one sequence
+// (live_prefix) cut into RT_QUEUES queues, one per XCD.
+#define RT_REGIONS_MAX 256u
 struct WfCtl {
-    uint32_t count[2];              // paths in pool 0 / 1
-    uint32_t gen_base, gen_count;   // refill: first free position and number of new paths
+    // ---- what the host reads back (RT_CTL_HEAD_BYTES) ----
+    uint32_t count_total[2];        // paths in pool 0 / 1 after the last refill of that pool
+    uint32_t gen_count, regions;    // refill: number of new paths; regions of this pass
     unsigned long long cursor;      // next path id to start
     unsigned long long gen_first;   // first path id of the current refill
     uint32_t gen_rem;               // path id of the refill's first path, modulo the paths per tile ...
     uint32_t gen_tile;              // ... and divided by them: the tile the refill starts in
     // closest-hit launch under RT_OPT_COUNTERS: earliest wave start, latest wave end, sum of wave ends (100 MHz ticks), waves that did work
     unsigned long long t_first, t_last, t_end_sum, n_worked;
-    uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per region, first entry no wave has claimed yet (one cache line each)
+    // ---- device only ----
+    uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per queue, first entry no wave has claimed yet (one cache line each)
+    uint32_t gen_base[RT_REGIONS_MAX];                  // per region: first place the current refill writes (= survivors in front of it)
+    uint32_t gen_prefix[RT_REGIONS_MAX + 1];            // new paths the refill gives to the regions before r
+    uint32_t live_prefix[RT_REGIONS_MAX + 1];           // live entries in the regions before r, after the refill
+    uint32_t count[2][RT_REGIONS_MAX * RT_QUEUE_STRIDE];   // entries in region r of pool k (one cache line each)
 };
+#define RT_CTL_HEAD_BYTES 72
+static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads back exactly the head of the control block");
 
-__global__ void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t capacity, uint32_t per_tile, unsigned long long* counters) {
-    if (threadIdx.x || blockIdx.x) return;
-    if (ctl->n_worked) {
+// One workgroup of RT_REGIONS_MAX threads, thread r for region r: sizes the refill of pool `nxt` (free room per region
+// against the paths not yet started), hands out the new path ids region after region, and lays out the closest-hit
+// launch's view of the pool.
+__global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t regions, uint32_t region_cap,
+                                                                 uint32_t per_tile, unsigned long long* counters) {
+    __shared__ uint32_t scan[RT_REGIONS_MAX];
+    const uint32_t r = threadIdx.x;
+    if (r == 0 && ctl->n_worked) {
         // fold the previous closest-hit launch's wave times: slot-ticks the launch spanned, and those left idle behind waves that ended early
         // (atomic: with two pipelines per pass, two planners may run at once)
         atomicAdd(&counters[RT_CNT_LAUNCH_SLOT_TICKS], (ctl->t_last - ctl->t_first) * ctl->n_worked);
         atomicAdd(&counters[RT_CNT_TAIL_IDLE_TICKS], ctl->t_last * ctl->n_worked - ctl->t_end_sum);
     }
-    ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
-    const uint32_t have = ctl->count[nxt];
+    const uint32_t have = r < regions ? ctl->count[nxt][r * RT_QUEUE_STRIDE] : 0u;
+    const uint32_t room = r < regions ? region_cap - have : 0u;
+    // exclusive prefix of the rooms: regions are filled in order until the paths run out
+    auto exclusive = [&](uint32_t v) {
+        scan[r] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < RT_REGIONS_MAX; d <<= 1) {
+            const uint32_t up = r >= d ? scan[r - d] : 0u;
+            __syncthreads();
+            scan[r] += up;
+            __syncthreads();
+        }
+        const uint32_t incl = scan[r];
+        __syncthreads();
+        return incl - v;
+    };
     const unsigned long long left = total - ctl->cursor;
-    const uint32_t room = capacity - have;
-    const uint32_t n = left < (unsigned long long)room ? (uint32_t)left : room;
-    ctl->gen_base = have;
-    ctl->gen_count = n;
-    ctl->gen_first = ctl->cursor;
-    ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
-    ctl->gen_tile = (uint32_t)(ctl->cursor / per_tile);
-    ctl->cursor += n;
-    ctl->count[nxt] = have + n;
-    ctl->count[nxt ^ 1] = 0;        // the pool just consumed becomes the next target
-    for (uint32_t k = 0; k < RT_QUEUES; k++) ctl->queue_next[k * RT_QUEUE_STRIDE] = 0;
+    const uint32_t before = exclusive(room);
+    const uint32_t given = (unsigned long long)before >= left ? 0u : (uint32_t)(left - before < (unsigned long long)room ? left - before : room);
+    const uint32_t new_before = exclusive(given);
+    const uint32_t live_before = exclusive(have + given);
+    __syncthreads();
+    if (r < regions) {
+        ctl->gen_base[r] = have;
+        ctl->gen_prefix[r] = new_before;
+        ctl->live_prefix[r] = live_before;
+        ctl->count[nxt][r * RT_QUEUE_STRIDE] = have + given;
+        ctl->count[nxt ^ 1][r * RT_QUEUE_STRIDE] = 0;     // the pool just consumed becomes the next target
+    }
+    if (r == regions - 1) {
+        const uint32_t n = new_before + given;
+        ctl->gen_prefix[regions] = n;
+        ctl->live_prefix[regions] = live_before + have + given;
+        ctl->count_total[nxt] = live_before + have + given;
+        ctl->count_total[nxt ^ 1] = 0;
+        ctl->gen_count = n;
+        ctl->regions = regions;
+        ctl->gen_first = ctl->cursor;
+        ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
+        ctl->gen_tile = (uint32_t)(ctl->cursor / per_tile);
+        ctl->cursor += n;
+        ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
+    }
+    if (r < RT_QUEUES) ctl->queue_next[r * RT_QUEUE_STRIDE] = 0;
 }
 
 // The shading kernel streams the pools: it reads every record once and writes every survivor once, and a pool is far
@@ -254,7 +306,11 @@ __device__ __forceinline__ void pool_store(float4* p, const float4 v) {
 
 // Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
 // tile's next sample, then the next tile, so consecutive waves trace neighbouring primary rays.
-__global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __restrict__ ctl, WfPools pools, int nxt, PathParams pp) {
+__global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __restrict__ ctl, WfPools pools, int nxt, uint32_t regions, uint32_t log2_region_cap,
+                                                               PathParams pp) {
+    __shared__ uint32_t new_before[RT_REGIONS_MAX + 1];
+    for (uint32_t k = threadIdx.x; k <= regions; k += RT_BLOCK) new_before[k] = ctl->gen_prefix[k];
+    __syncthreads();
     uint32_t n_paths = 0;
     // the grid is sized for the chip, not for the pool (half a million workgroups of which most find nothing to do cost
     // more than the writing): a workgroup strides over the new paths
@@ -271,7 +327,13 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
         const int wave = p >> 6, lane = p & 63;
         const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
         const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-        const uint32_t pos = ctl->gen_base + j;
+        // the region that takes new path j: the last one whose share starts at or before j
+        uint32_t lo = 0, hi = regions - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t pos = (lo << log2_region_cap) + ctl->gen_base[lo] + (j - new_before[lo]);
         const int sample = pp.first_sample + (int)s;
         int depth = pp.max_depth;
         v3 dir = mk3(0.0f, 0.0f, 1.0f);
@@ -325,13 +387,17 @@ template <bool COUNT, bool VOTE>
 __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
                                                              int vote_leaf_weight, int refill_min, float cam_x, float cam_y, float cam_z,
-                                                             unsigned long long* counters) {
+                                                             uint32_t regions, uint32_t log2_region_cap, unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
     // behind the stacks, inside the one dynamic LDS block: copies of the first n_hot node records
     const uint32_t block = blockDim.x;
     lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * block);
-    const uint32_t count = ctl->count[nxt];
+    // behind those: where each region's live entries start in the launch's one sequence of entries (regions + 1 words)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* live = (lds_u32*)((__attribute__((address_space(3))) char*)hot + (size_t)n_hot * RT_HOT_STRIDE);
+    for (uint32_t k = threadIdx.x; k <= regions; k += block) live[k] = ctl->live_prefix[k];
+    const uint32_t count = ctl->count_total[nxt];
     TravCounters tc = {};
     for (uint32_t k = threadIdx.x; k < n_hot * 7u; k += block) {
         const uint32_t node = k / 7u, piece = k - node * 7u;
@@ -350,8 +416,9 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     Hit h;
     h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.tri = REF_NONE;
     int ridx = -1;                                 // pool entry this lane is tracing, -1 = none
-    uint32_t next = 0, end = 0;                    // wave-uniform: the unclaimed rest of this wave's chunk
-    uint32_t queue = blockIdx.x & (RT_QUEUES - 1u);  // wave-uniform: the region this wave draws from
+    uint32_t next = 0, end = 0;                    // wave-uniform: the unclaimed rest of this wave's chunk (places in the sequence of live entries)
+    uint32_t reg = 0;                              // wave-uniform: the pool region that holds entry `next`
+    uint32_t queue = blockIdx.x & (RT_QUEUES - 1u);  // wave-uniform: the part of the sequence this wave draws from
     const uint32_t region = ((count + RT_QUEUES - 1u) / RT_QUEUES + 63u) & ~63u;
     unsigned long long cyc_claim = 0, n_claim = 0;
     bool exhausted = false;                        // wave-uniform: the queue has nothing left
@@ -375,6 +442,13 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
                     next = region_begin + base;
                     end = min(region_end, next + size);
                     got = true;
+                    // the pool region `next` lies in: the last one that starts at or before it (empty regions start where the next one does)
+                    uint32_t lo = 0, hi = regions - 1u;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (live[mid] <= next) lo = mid; else hi = mid - 1u;
+                    }
+                    reg = lo;
                 } else {
                     queue = (queue + 1u) & (RT_QUEUES - 1u);
                 }
@@ -384,8 +458,12 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
         // The lanes that take a new ray get it through selects at the end, not by assignments inside the branch: the ray and
         // the walk state then have one home register each for the whole trip loop (assigned in a branch, the new values
         // would live beside the old ones and every trip would end with some forty register copies).
-        const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const bool take = idle && idx < end;
+        const uint32_t seq = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const bool take = idle && seq < end;
+        // place in the sequence -> place in the pool: a chunk may run over the end of a region into the next non-empty one
+        uint32_t rr = reg;
+        while (take && seq >= live[rr + 1u]) rr++;
+        const uint32_t idx = (rr << log2_region_cap) + (seq - live[rr]);
         float4 a = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(0xFFFFFFFFu));
         float4 b = make_float4(cam_x, cam_y, cam_z, 0.0f);          // a new path starts at the camera and has no second record
         if (take) {
@@ -410,6 +488,7 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
         r.o_xy = trace ? rn.o_xy : r.o_xy; r.o_zx = trace ? rn.o_zx : r.o_zx; r.o_yz = trace ? rn.o_yz : r.o_yz;
         r.i_xy = trace ? rn.i_xy : r.i_xy; r.i_zx = trace ? rn.i_zx : r.i_zx; r.i_yz = trace ? rn.i_yz : r.i_yz;
         next = min(end, next + (uint32_t)__popcll(m));
+        while (next < end && next >= live[reg + 1u]) reg++;
     };
     unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0;
     const unsigned long long cyc_begin = COUNT ? clock64() : 0ull;
@@ -491,22 +570,26 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     }
 }
 
-// Workgroups of 1024 lanes: the survivors of all 16 waves are numbered through LDS and the workgroup takes its
-// range of the next pool with ONE returning atomic -- a returning atomic on a single word sustains only ~90 per
-// microsecond chip-wide, so one per wave (262k per iteration of a 16M-path pool) would cost more than the shading.
-#define RT_SHADE_BLOCK 1024
-static_assert(RT_SHADE_BLOCK == 1024, "wf_shade_kernel's offset scan handles 8 octants x 16 waves = 128 counts, two per lane of wave 0");
+// Shading and queue compaction.  Workgroup b reads 256 consecutive entries of region (b mod regions) of pool `cur` --
+// workgroups that run at the same time read different regions -- and every wave files its survivors at the front of the
+// same region of the other pool: 64-bit ballot, lane prefix count, ONE returning atomic per wave on that region's own
+// counter.  No LDS, no barrier.  (A counter shared by the whole chip was the bottleneck of two earlier designs: a
+// returning atomic on one word sustains ~90 per microsecond, and the barriers around a per-workgroup claim stalled
+// 1024-lane workgroups as a whole.)
+#define RT_SHADE_BLOCK 256
 template <bool COUNT>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, PathParams pp) {
-    __shared__ uint32_t bin_count[8 * (RT_SHADE_BLOCK / 64)];   // survivors per [direction octant][wave], then their offsets
-    __shared__ uint32_t wave_finished[RT_SHADE_BLOCK / 64];
-    __shared__ uint32_t block_base;
-    const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, uint32_t regions, uint32_t log2_region_cap,
+                                                                  PathParams pp) {
+    const uint32_t reg = blockIdx.x % regions, within = blockIdx.x / regions;
+    const uint32_t local = within * RT_SHADE_BLOCK + threadIdx.x;          // place inside the region
+    const uint32_t live = ctl->count[cur][reg * RT_QUEUE_STRIDE];
+    if (within * RT_SHADE_BLOCK >= live) return;                             // nothing of this region is left for this workgroup
+    const uint32_t i = (reg << log2_region_cap) + local;
     const int nxt = cur ^ 1;
     uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0;
     bool survives = false;
     float4 o0, o1, o2;
-    if (i < ctl->count[cur]) {
+    if (local < live) {
         const float4 a = pool_load(&pools.p0[cur][i]), hq = pool_load(&pools.hit[i]);
         const uint32_t word = __float_as_uint(a.w);
         if ((int)word >= 0) {                                        // -1: nothing was traced for this entry
@@ -517,7 +600,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
             int sample;
             if (word & RT_FRESH_PATH) {
-                const uint32_t rem = ctl->gen_rem + (i - ctl->gen_base);
+                const uint32_t rem = ctl->gen_rem + ctl->gen_prefix[reg] + (local - ctl->gen_base[reg]);
                 sample = pp.first_sample + (int)((rem % ((uint32_t)pp.n_samples * 256u)) >> 8);
             } else {
                 b = pool_load(&pools.p1[cur][i]);
@@ -555,54 +638,24 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             }
         }
     }
-    // Queue compaction, ordered by direction octant: the workgroup's survivors leave in 8 groups (sign bits of the
-    // new direction), so that the waves of the next closest-hit launch hold rays that start close together (same
-    // few pixel tiles) AND point the same way -- they then walk the same nodes.  Per wave: one 64-bit ballot per
-    // octant; counts [octant][wave] through LDS; wave 0 turns them into offsets with one shuffle scan; one returning
-    // atomic per workgroup.  With pp.sort_rays == 0 every survivor is filed under octant 0: plain order.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t oct = 0;
-    if (survives && pp.sort_rays) oct = (o0.x < 0.0f ? 1u : 0u) | (o0.y < 0.0f ? 2u : 0u) | (o0.z < 0.0f ? 4u : 0u);
-    uint32_t rank = 0;
-    for (uint32_t o = 0; o < 8u; o++) {
-        const unsigned long long m = __ballot(survives && oct == o);
-        if (lane == 0) bin_count[o * (RT_SHADE_BLOCK / 64) + wave] = (uint32_t)__popcll(m);
-        if (survives && oct == o) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    }
-    const unsigned long long done = __ballot(n_paths != 0);
-    const unsigned long long traced = __ballot(n_rays != 0);
-    if (lane == 0) wave_finished[wave] = (uint32_t)__popcll(done) | ((uint32_t)__popcll(traced) << 16);   // both <= 64
-    __syncthreads();
-    if (wave == 0) {
-        // 128 counts, octant-major: lane l owns entries 2l and 2l+1
-        const uint32_t c0 = bin_count[2 * lane], c1 = bin_count[2 * lane + 1];
-        uint32_t incl = c0 + c1;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        const uint32_t excl = incl - (c0 + c1);
-        bin_count[2 * lane] = excl;
-        bin_count[2 * lane + 1] = excl + c0;
-        const uint32_t total = __shfl(incl, 63, 64);
-        uint32_t fr = lane < RT_SHADE_BLOCK / 64 ? wave_finished[lane] : 0u;   // packed sums stay below 2^16 each
-        for (int d = 32; d > 0; d >>= 1) fr += __shfl_xor(fr, d, 64);
-        if (lane == 0) {
-            block_base = total ? atomicAdd(&ctl->count[nxt], total) : 0u;
-            const uint32_t fin = fr & 0xFFFFu, rays = fr >> 16;
-            // finished paths and traced rays (one closest-hit query per live path): every workgroup adds its sums, so
-            // the additions are spread over RT_CNT_SPREAD cache lines -- on one word they would queue up behind each other
-            unsigned long long* spread = pp.counters + RT_CNT_COUNT + (blockIdx.x & (RT_CNT_SPREAD - 1u)) * RT_CNT_SPREAD_STRIDE;
-            if (fin) atomicAdd(spread, (unsigned long long)fin);
-            if (rays) atomicAdd(spread + 1, (unsigned long long)rays);
-        }
-    }
-    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(survives);
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(&ctl->count[nxt][reg * RT_QUEUE_STRIDE], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (survives) {
-        const uint32_t pos = block_base + bin_count[oct * (RT_SHADE_BLOCK / 64) + wave] + rank;
+        const uint32_t pos = (reg << log2_region_cap) + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         pool_store(&pools.p0[nxt][pos], o0);
         pool_store(&pools.p1[nxt][pos], o1);
         pool_store(&pools.p2[nxt][pos], o2);
+    }
+    // finished paths and traced rays (one closest-hit query per live path): every wave adds its sums, spread over
+    // RT_CNT_SPREAD cache lines -- on one word the additions would queue up behind each other
+    const uint32_t fin = (uint32_t)__popcll(__ballot(n_paths != 0)), rays = (uint32_t)__popcll(__ballot(n_rays != 0));
+    if (lane == 0) {
+        unsigned long long* spread = pp.counters + RT_CNT_COUNT + ((blockIdx.x * (RT_SHADE_BLOCK / 64) + (threadIdx.x >> 6)) & (RT_CNT_SPREAD - 1u)) * RT_CNT_SPREAD_STRIDE;
+        if (fin) atomicAdd(spread, (unsigned long long)fin);
+        if (rays) atomicAdd(spread + 1, (unsigned long long)rays);
     }
     if (COUNT) {
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
@@ -1089,7 +1142,12 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const uint32_t rpb = (uint32_t)ctx->opt_wf_run;
     const uint32_t eb = (uint32_t)ctx->opt_wf_block;
     const uint32_t n_hot = (uint32_t)std::min<uint64_t>((uint64_t)ctx->opt_hot_nodes, ctx->stats[1]);
-    const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE;
+    // regions of the pool: as many as RT_REGIONS_MAX, each a whole number of shading workgroups
+    uint32_t regions = RT_REGIONS_MAX;
+    while (regions > 1 && cap / regions < RT_SHADE_BLOCK) regions >>= 1;
+    uint32_t log2_region_cap = 0;
+    while ((1u << log2_region_cap) < cap / regions) log2_region_cap++;
+    const size_t elds = (size_t)slots_lds * eb * sizeof(uint2) + (size_t)n_hot * RT_HOT_STRIDE + (((size_t)regions + 1) * sizeof(uint32_t) + 15) / 16 * 16;
     if (elds > ctx->extend_lds_limit) {               // more than the default 64 KB of dynamic LDS has to be asked for once
         if (elds > 160u * 1024u) return fail(RT_ERR_INVALID, "rt_raytrace: stack slots and hot nodes need more than 160 KB of LDS per workgroup");
         HIP_TRY(hipFuncSetAttribute((const void*)wf_extend_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds));
@@ -1138,19 +1196,21 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             const int nxt = R.cur ^ 1;
             if (R.iter > 0) {
                 const int tk = timing_begin(ctx, 1, ls);
-                if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, R.pp);
-                else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, R.pp);
+                if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
+                else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 timing_end(ctx, tk, ls);
             }
-            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(64), 0, ls, L.d_ctl, nxt, R.total, cap, (uint32_t)R.pp.n_samples * 256u, ctx->d_counters);
-            hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, R.pp);
+            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, (uint32_t)R.pp.n_samples * 256u,
+                               ctx->d_counters);
+            hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, regions, log2_region_cap, R.pp);
             const int tke = timing_begin(ctx, 0, ls);
             {
                 // four builds of one kernel: with or without the counters, with the per-trip vote or the fixed node burst
                 auto kernel = ctx->opt_counters ? (ctx->opt_wf_vote ? wf_extend_kernel<true, true> : wf_extend_kernel<true, false>)
                                                 : (ctx->opt_wf_vote ? wf_extend_kernel<false, true> : wf_extend_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
-                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2], ctx->d_counters);
+                                   slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2],
+                                   regions, log2_region_cap, ctx->d_counters);
             }
             timing_end(ctx, tke, ls);
             HIP_TRY(hipGetLastError());
@@ -1160,13 +1220,13 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             // a group of work while the host waits; the price is one group of empty launches at the very end.
             if ((R.iter % RT_CTL_GROUP) == RT_CTL_GROUP - 1) {
                 const unsigned g = R.iter / RT_CTL_GROUP;
-                HIP_TRY(hipMemcpyAsync(&L.h_ctl[g % RT_CTL_RING], L.d_ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, ls));
+                HIP_TRY(hipMemcpyAsync(&L.h_ctl[g % RT_CTL_RING], L.d_ctl, RT_CTL_HEAD_BYTES, hipMemcpyDeviceToHost, ls));
                 HIP_TRY(hipEventRecord(L.ctl_ev[g % RT_CTL_RING], ls));
                 R.snap_cur[g % RT_CTL_RING] = R.cur;
                 if (g > 0) {
                     const unsigned q = (g - 1) % RT_CTL_RING;
                     HIP_TRY(hipEventSynchronize(L.ctl_ev[q]));
-                    if (L.h_ctl[q].cursor >= R.total && L.h_ctl[q].count[R.snap_cur[q]] == 0) { R.drained = true; live--; }
+                    if (L.h_ctl[q].cursor >= R.total && L.h_ctl[q].count_total[R.snap_cur[q]] == 0) { R.drained = true; live--; }
                 }
             }
             if (++R.iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");

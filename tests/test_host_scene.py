@@ -380,3 +380,44 @@ def test_tracked_benchmark_scene_files_are_what_the_generator_writes(tmp_path):
         tracked = open(os.path.join(root, "benchmarks", "scenes", f"scene_{name}.txt")).read()
         assert open(path).read() == tracked
         assert "size 400 240" in tracked if name == "luyu" else "simple_material" in tracked
+
+
+def test_material_table_and_ids_by_hand(tmp_path):
+    """Expectations written out by hand from upstream's text (csrc/sceneloader.cpp:132-219), independent of
+    raytrace_amd.scene: one render object per shape; the block's own material first, then one per MTL record in file
+    order; a face's id = block offset + MTL index + 1, or the block's own material when the face has none; illum 1..5 ->
+    lambertian, metal, light, refractive, reflective (anything else lambertian); a light takes Ke, the others Kd; a
+    refractive record takes Ni as optical density -- which then stays in force for the records after it -- and the albedo
+    (1-d) + d*Kd; metal_fuzz is the block's for every record; `simple_material` gives every face the block's own."""
+    d = tmp_path / "hand"
+    d.mkdir()
+    (d / "m.mtl").write_text(
+        "newmtl red\nillum 1\nKd 1 0 0\n\n"
+        "newmtl lamp\nillum 3\nKd 0.5 0.5 0.5\nKe 4 5 6\n\n"
+        "newmtl glass\nillum 4\nKd 0.5 1 0\nNi 1.5\nd 0.25\n\n"
+        "newmtl mirror\nillum 5\nKd 0.9 0.8 0.7\nNi 9\n\n"
+        "newmtl odd\nillum 7\nKd 0.1 0.2 0.3\n")
+    (d / "two.obj").write_text(
+        "mtllib m.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n"
+        "o first\nf 1 2 3\nusemtl glass\nf 1 2 4\nusemtl red\nf 1 3 4\n"
+        "o second\nusemtl mirror\nf 2 3 4\n")
+    block = ("object\n path {0}/two.obj\n mtldir {0}\n type metal\n albedo 0.3 0.3 0.3\n optical_density 2\n metal_fuzz 0.125\n{1}end\n")
+    text = BASE + block.format(d, "") + block.format(d, " simple_material\n") + "end\n"
+    p = d / "scene.txt"
+    p.write_text(text)
+    r, out = load_with_cpp(str(p), tmp_path)
+    assert r.returncode == 0, r.stderr
+    s = summary(r.stdout)
+    assert s["objects"][0] == "4" and s["objects"][2] == "7"          # 2 shapes per block; 1 + 5 materials, then 1 (simple_material adds no MTL records)
+    m = np.fromfile(str(out / "materials.bin"), dtype=capi.MATERIAL_DTYPE)
+    L, ME, LI, RA, RE = capi.MAT_LAMBERTIAN, capi.MAT_METAL, capi.MAT_LIGHT, capi.MAT_REFRACTIVE, capi.MAT_REFLECTIVE
+    assert list(m["type"]) == [ME, L, LI, RA, RE, L, ME]
+    f = np.float32
+    assert same_f32(m["albedo"], np.array([[0.3, 0.3, 0.3], [1, 0, 0], [4, 5, 6],
+                                           [f(0.75) + f(0.25) * f(0.5), f(0.75) + f(0.25) * f(1), f(0.75) + f(0.25) * f(0)],
+                                           [0.9, 0.8, 0.7], [0.1, 0.2, 0.3], [0.3, 0.3, 0.3]], dtype=np.float32))
+    assert list(m["optical_density"]) == [2, 2, 2, 1.5, 1.5, 1.5, 2]   # Ni of the glass record carries over to mirror and odd, not Ni 9
+    assert (m["metal_fuzz"] == f(0.125)).all() and (m["texture"] == -1).all()
+    ids = [list(np.fromfile(str(out / f"tri{i}.bin"), dtype=capi.TRIANGLE_DTYPE)["material_id"]) for i in range(4)]
+    assert ids == [[0, 3, 1], [4], [6, 6, 6], [6]]                      # block 1: own, glass (0+2+1), red (0+0+1); mirror (0+3+1); block 2: all its own (offset 6)
