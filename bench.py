@@ -402,7 +402,8 @@ def main():
                          "demand_note": "32*box_tests + 36*triangle_tests per ray: requested of LDS/L1/L2/Infinity Cache, not of HBM",
                          "counter_passes": pmc_source},
             "binding": binding,
-            "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "shade_ms": round(tim["shade_ms"], 2),
+            "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "extend_launches": tim["extend_launches"],
+                             "shade_ms": round(tim["shade_ms"], 2), "shade_launches": tim["shade_launches"],
                              "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},
             "source_hash": source_hash(), "workload_key": workload_key(args, cfg),
             "published_reference": {"seconds_per_frame": 70, "hardware": "RTX 4090", "note": "upstream README.md:21, different geometry"},

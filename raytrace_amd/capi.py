@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtcore.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librtcore.so")     # RT_LIB: another build of the same library (A/B runs)
 
 # numpy views of the upstream host layouts (include/rtcore.h)
 VERTEX_DTYPE = np.dtype(

@@ -576,7 +576,9 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
 // counter.  No LDS, no barrier.  (A counter shared by the whole chip was the bottleneck of two earlier designs: a
 // returning atomic on one word sustains ~90 per microsecond, and the barriers around a per-workgroup claim stalled
 // 1024-lane workgroups as a whole.)
+#ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, uint32_t regions, uint32_t log2_region_cap,
                                                                   PathParams pp) {

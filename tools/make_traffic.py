@@ -46,6 +46,8 @@ def kernel_ms(bench_json, kernel):
     r = d.get("roofline", {})
     if r.get("kernel") == kernel:
         return r.get("kernel_ms_mean")
+    if kernel == "wf_shade_kernel" and ks.get("shade_launches"):
+        return round(ks["shade_ms"] / ks["shade_launches"], 4)
     return None
 
 
