@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
     ap.add_argument("--wf-lanes", type=int, default=0)
+    ap.add_argument("--hot-tune", type=int, default=-1, help="1/0: number the LDS-resident node records by measured visits (default: library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the scene tree on the device (RT_OPT_GPU_BVH) instead of re-packing upstream's trees")
     ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
     args = ap.parse_args()
@@ -200,6 +201,8 @@ def main():
         ctx.set_option(capi.OPT_WF_BLOCK, args.wf_block)
     if args.wf_lanes:
         ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
+    if args.hot_tune >= 0:
+        ctx.set_option(capi.OPT_HOT_TUNE, args.hot_tune)
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height

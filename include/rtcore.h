@@ -148,6 +148,11 @@ enum {
                                  one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);
                                  scheduling only */
     RT_OPT_WF_BURST = 9,      /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
+    RT_OPT_HOT_TUNE = 18,     /* wavefront: 1 (default) = before the first call of at least 64 samples per pixel after a scene upload or a camera
+                                 change, one sample per pixel is traced to count the visits of the 4096 node records nearest the root, and
+                                 those records are renumbered by falling count, so that the records the closest-hit kernel keeps in LDS
+                                 (RT_OPT_HOT_NODES) are the ones this view enters most; 0 = static order (largest boxes first).
+                                 Scheduling only: node numbers are addresses */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (Morton-code LBVH, rocPRIM sorts): a load-time option for large scenes, replacing

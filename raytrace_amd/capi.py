@@ -42,6 +42,7 @@ OPT_WF_REFILL = 14
 OPT_WF_BLOCK = 15
 OPT_WF_LANES = 16
 OPT_GPU_BVH = 17
+OPT_HOT_TUNE = 18
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 GROUP_ID_BYTES = 128

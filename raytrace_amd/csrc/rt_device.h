@@ -40,7 +40,8 @@ struct PathParams {
     int tiles_x, tiles_y;
     int xcd_remap;
     int lds_slots;                        // stack levels kept in LDS
-    int sort_rays;                        // wavefront: order each workgroup's surviving rays by direction octant
+    int sort_rays;                        // unused (the compaction no longer orders by direction octant)
+    uint32_t* hist;                       // calibration pass only: per-node visit counts (see TravCounters), else null
 };
 
 #define RT_BLOCK 256
@@ -179,8 +180,10 @@ typedef __attribute__((address_space(3))) f4v lds_float4;   // native vector typ
 // on, so lanes that read the same 16-byte piece of different nodes spread over the banks.
 #define RT_HOT_STRIDE 112
 
+#define RT_HIST_NODES 4096u          // node records whose visits the calibration pass counts one by one (the candidates for the LDS copy)
 struct TravCounters {
     uint32_t n_box, n_tri, max_sp, w_node, w_leaf, n_node, n_hot_visit, ray_visits, max_ray_visits, n_nonfinite;
+    uint32_t* hist;                  // counting builds only: visits per node record below RT_HIST_NODES, or null
 };
 
 // The walk, one step at a time, so that kernels can interleave it with other work (refilling idle lanes).
@@ -282,6 +285,7 @@ struct Walker {
             tc.n_node++;
             tc.ray_visits++;
             tc.n_hot_visit += cur < n_hot;
+            if (tc.hist && cur < RT_HIST_NODES) atomicAdd(tc.hist + cur, 1u);
             // one lane per wave counts the trip: sum over lanes = trips the wave executed
             if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) tc.w_node++;
         }

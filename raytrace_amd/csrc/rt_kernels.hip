@@ -20,6 +20,7 @@
 // Built with -ffp-contract=off; expressions keep upstream's operand order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
 
     uint32_t n_rays = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
     TravCounters tc = {};
+    tc.hist = pp.hist;
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -719,6 +721,20 @@ __global__ __launch_bounds__(RT_BLOCK) void post_process_kernel(int n_pixels, in
     }
 }
 
+// Renumbering of the first `k` node records (the candidates for the closest-hit kernel's LDS copy): record i moves to
+// place perm[i]; references among the first k follow.  No record beyond k refers to one of the first k: parents always
+// carry lower numbers than their children.
+__global__ __launch_bounds__(RT_BLOCK) void permute_nodes_kernel(const Node4* __restrict__ nodes, uint32_t k, const uint32_t* __restrict__ perm, Node4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= k) return;
+    Node4 nd = nodes[i];
+    for (int slot = 0; slot < 4; slot++) {
+        const uint32_t r = nd.ref[slot];
+        if (r != REF_NONE && !(r & REF_LEAF) && r < k) nd.ref[slot] = perm[r];
+    }
+    out[perm[i]] = nd;
+}
+
 // ---------------------------------------------------------------------------
 // context and C ABI
 // ---------------------------------------------------------------------------
@@ -751,6 +767,9 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
+    int opt_hot_tune = 1;            // wavefront: number the node records by measured visits before a frame (one calibration sample per pixel)
+    bool hot_dirty = true;           // scene or camera changed since the node numbering was last tuned
+    void* d_tune = nullptr;          // calibration scratch: visit counts, throw-away counters, permutation, a copy of the candidate records
     int opt_gpu_bvh = 0;             // 1 = rt_upload_scene builds its own tree on the device instead of re-packing the caller's
     int opt_lds_slots = 11;          // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
@@ -896,6 +915,7 @@ int rt_destroy(rt_context* ctx) {
     free_scene(ctx);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->d_tune) (void)hipFree(ctx->d_tune);
     free_pools(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -909,6 +929,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
     case RT_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return RT_OK;
     case RT_OPT_GPU_BVH: ctx->opt_gpu_bvh = value ? 1 : 0; return RT_OK;
+    case RT_OPT_HOT_TUNE: ctx->opt_hot_tune = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
@@ -1042,6 +1063,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->stats[3] = bytes;
     ctx->stats[4] = (uint64_t)n_objects;
     ctx->have_scene = true;
+    ctx->hot_dirty = true;
     return RT_OK;
 }
 
@@ -1062,6 +1084,7 @@ int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera
     ctx->width = width;
     ctx->height = height;
     ctx->have_camera = true;
+    ctx->hot_dirty = true;
     return RT_OK;
 }
 
@@ -1241,6 +1264,52 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     return RT_OK;
 }
 
+// Which node records the closest-hit kernel should keep in LDS depends on the scene AND the camera: the records rays
+// enter most.  The static numbering (largest boxes first) is a guess; this measures.  One sample per pixel is traced
+// with the counting build of the megakernel -- same rays, same walk as the frame's -- into a histogram of visits over
+// the first RT_HIST_NODES records, and those records are renumbered by falling count (ties: old order).  Node numbers
+// are only addresses: no result changes.  Costs one sample per pixel (a few milliseconds) and a stream
+// synchronisation, so it runs once per scene and camera, and only for calls of at least RT_TUNE_MIN_SPP samples.
+#define RT_TUNE_MIN_SPP 64
+static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
+    const uint32_t k = (uint32_t)std::min<uint64_t>(RT_HIST_NODES, ctx->stats[1]);
+    if (k < 2) return RT_OK;
+    const size_t hist_bytes = RT_HIST_NODES * sizeof(uint32_t), cnt_bytes = RT_CNT_WORDS * sizeof(unsigned long long);
+    const size_t perm_at = hist_bytes + cnt_bytes, copy_at = perm_at + hist_bytes;
+    if (!ctx->d_tune) HIP_TRY(hipMalloc(&ctx->d_tune, copy_at + RT_HIST_NODES * sizeof(Node4)));
+    char* base = (char*)ctx->d_tune;
+    uint32_t* d_hist = (uint32_t*)base;
+    uint32_t* d_perm = (uint32_t*)(base + perm_at);
+    Node4* d_copy = (Node4*)(base + copy_at);
+    HIP_TRY(hipMemsetAsync(base, 0, hist_bytes + cnt_bytes, s));
+    pp.n_samples = 1;
+    pp.chunk = 1;
+    pp.n_chunks = 1;
+    pp.counters = (unsigned long long*)(base + hist_bytes);      // the calibration's rays are not the frame's: counted apart and dropped
+    pp.hist = d_hist;
+    const long long nblocks = (long long)pp.tiles_x * pp.tiles_y;
+    hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hist(k), order(k), perm(k);
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < k; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&hist](uint32_t a, uint32_t b) { return hist[a] > hist[b]; });
+    bool moved = false;
+    for (uint32_t at = 0; at < k; at++) { perm[order[at]] = at; moved = moved || order[at] != at; }
+    if (moved) {
+        HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(permute_nodes_kernel, dim3((k + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, (const Node4*)ctx->d_nodes, k, (const uint32_t*)d_perm, d_copy);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->d_nodes, d_copy, (size_t)k * sizeof(Node4), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                         // `perm` leaves scope
+        uint32_t& root = ctx->dev.root.ref;
+        if (root != REF_NONE && !(root & REF_LEAF) && root < k) root = perm[root];
+    }
+    ctx->hot_dirty = false;
+    return RT_OK;
+}
+
 // Body of rt_raytrace and rt_raytrace_static.  `fixed_slots` == nullptr: the slot buffer belongs to the context and grows
 // on demand, the context's kernel design is used.  Otherwise the slots are `fixed_bytes` of memory the caller of this
 // function provides, nothing is allocated, created or freed, and every pass is one path_kernel launch.
@@ -1304,7 +1373,13 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.chunk = ctx->opt_chunk;
     pp.lds_slots = lds_slots(ctx);
     pp.sort_rays = ctx->opt_wf_sort;
+    pp.hist = nullptr;
     const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
+    if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
+        pp.first_sample = first_sample;
+        const int rc = tune_hot_nodes(ctx, pp, s);
+        if (rc) return rc;
+    }
     for (int done = 0; done < spp; done += pass) {
         pp.first_sample = first_sample + done;
         pp.n_samples = spp - done < pass ? spp - done : pass;

@@ -486,3 +486,31 @@ def test_stress_scene_at_its_real_size(gpu_ctx):
     assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
     assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2] and gcnt[capi.CNT_SHADED] == rcnt[3]
     assert gcnt[capi.CNT_MAX_STACK] > 11                                      # the private spill levels were in use
+
+
+def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
+    """The calibration pass (one sample per pixel counted into a visit histogram, the 4096 records nearest the root
+    renumbered by falling count) only moves records: same image, same counts, and more node visits served from LDS."""
+    asm = scene.formula1(width=200, height=120, n_samples=64, detail=0.15, tex_size=64)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 18)
+    try:
+        out = {}
+        for tune in (0, 1):
+            gpu_ctx.set_option(capi.OPT_HOT_TUNE, tune)
+            p = Pair(gpu_ctx, asm)                                  # uploads again: the static numbering is back
+            out[tune] = p.gpu_render(0, 64, 16)
+            if tune:
+                again = p.gpu_render(0, 64, 16)                     # second frame, same camera: no new calibration, same picture
+                assert same_f32(again[0], out[1][0])
+                hits_tuned = p.check_hits(orc.primary_rays(orc.make_params(p.cfg, SEED, 16), 0))     # rt_closest_hit on the renumbered records
+                assert (hits_tuned >= 0).any()
+    finally:
+        gpu_ctx.set_option(capi.OPT_HOT_TUNE, 1)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    (a, ca), (b, cb) = out[0], out[1]
+    assert same_f32(a, b)
+    for k in (capi.CNT_RAYS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS, capi.CNT_NODE_VISITS):
+        assert ca[k] == cb[k], k
+    assert cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
