@@ -317,6 +317,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
     // the grid is sized for the chip, not for the pool (half a million workgroups of which most find nothing to do cost
     // more than the writing): a workgroup strides over the new paths
     const uint32_t gen_count = ctl->gen_count;
+    uint32_t reg = RT_REGIONS_MAX;       // the region that took this thread's last path; none yet
     for (uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x; j < gen_count; j += gridDim.x * RT_BLOCK) {
         // path id = gen_first + j, taken apart with 32-bit arithmetic: the planner has divided the first id already
         const uint32_t per_tile = (uint32_t)pp.n_samples * 256u;
@@ -329,13 +330,19 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
         const int wave = p >> 6, lane = p & 63;
         const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
         const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-        // the region that takes new path j: the last one whose share starts at or before j
-        uint32_t lo = 0, hi = regions - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
+        // the region that takes new path j: the last one whose share starts at or before j -- searched for the thread's
+        // first path, stepped to for its later ones (j only grows, by less than a few regions' shares at a time)
+        if (reg == RT_REGIONS_MAX) {
+            uint32_t lo = 0, hi = regions - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            reg = lo;
+        } else {
+            while (reg + 1 < regions && new_before[reg + 1] <= j) reg++;
         }
-        const uint32_t pos = (lo << log2_region_cap) + ctl->gen_base[lo] + (j - new_before[lo]);
+        const uint32_t pos = (reg << log2_region_cap) + ctl->gen_base[reg] + (j - new_before[reg]);
         const int sample = pp.first_sample + (int)s;
         int depth = pp.max_depth;
         v3 dir = mk3(0.0f, 0.0f, 1.0f);
