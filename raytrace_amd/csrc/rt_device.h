@@ -42,7 +42,22 @@ struct PathParams {
     int lds_slots;                        // stack levels kept in LDS
     int sort_rays;                        // unused (the compaction no longer orders by direction octant)
     uint32_t* hist;                       // calibration pass only: per-node visit counts (see TravCounters), else null
+    // wavefront: divisors the refill and the shading kernel divide path numbers by, with floor(2^32 / divisor) beside them
+    uint32_t per_tile, per_tile_magic;    // paths of one 16x16 tile in this pass = n_samples * 256
+    uint32_t tiles_x_magic, batch_magic;
 };
+
+// x / d for a divisor the whole launch shares, with m = floor(2^32 / d) from the host: the estimate mulhi(x, m) is the
+// quotient or one below it (two corrections allowed for), which costs a multiply instead of the ~35 instructions of a
+// 32-bit division
+__device__ __forceinline__ uint32_t udiv_by(uint32_t x, uint32_t d, uint32_t m, uint32_t& rem) {
+    uint32_t q = __umulhi(x, m);
+    uint32_t r = x - q * d;
+    if (r >= d) { q++; r -= d; }
+    if (r >= d) { q++; r -= d; }
+    rem = r;
+    return q;
+}
 
 #define RT_BLOCK 256
 #define RT_INF __builtin_inff()

@@ -308,61 +308,80 @@ __device__ __forceinline__ void pool_store(float4* p, const float4 v) {
 
 // Path id -> (tile, sample of the pass, pixel of the 16x16 tile): ids walk a tile's 256 pixels, then the
 // tile's next sample, then the next tile, so consecutive waves trace neighbouring primary rays.
+// The samples of one semantic batch share their primary ray (cuda/raytrace.cu:210), so a thread does not take one path
+// but one pixel's run of RT_GEN_RUN consecutive samples of a tile: the jitter draw, the two true divisions and the
+// normalisation are done once per batch, and each of the run's paths costs a store.  (One thread per path spent 250
+// vector instructions on every 16-byte record: 0.40 ms per refill where the writing takes 0.15.)
+#define RT_GEN_RUN 64u
 __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __restrict__ ctl, WfPools pools, int nxt, uint32_t regions, uint32_t log2_region_cap,
                                                                PathParams pp) {
     __shared__ uint32_t new_before[RT_REGIONS_MAX + 1];
     for (uint32_t k = threadIdx.x; k <= regions; k += RT_BLOCK) new_before[k] = ctl->gen_prefix[k];
     __syncthreads();
     uint32_t n_paths = 0;
-    // the grid is sized for the chip, not for the pool (half a million workgroups of which most find nothing to do cost
-    // more than the writing): a workgroup strides over the new paths
-    const uint32_t gen_count = ctl->gen_count;
-    uint32_t reg = RT_REGIONS_MAX;       // the region that took this thread's last path; none yet
-    for (uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x; j < gen_count; j += gridDim.x * RT_BLOCK) {
-        // path id = gen_first + j, taken apart with 32-bit arithmetic: the planner has divided the first id already
-        const uint32_t per_tile = (uint32_t)pp.n_samples * 256u;
-        const uint32_t along = ctl->gen_rem + j;            // below 2^32: per_tile <= 2^31 and j < 2^28
-        const uint32_t over = along / per_tile;
-        const uint32_t tile = ctl->gen_tile + over;
-        const uint32_t rem = along - over * per_tile;
-        const uint32_t s = rem >> 8, p = rem & 255u;
-        const int tx = tile % pp.tiles_x, ty = tile / pp.tiles_x;
+    const uint32_t gen_count = ctl->gen_count, gen_rem = ctl->gen_rem;
+    // the refill's ids, counted from the start of its first tile: [gen_rem, gen_rem + gen_count); the tiles they touch
+    uint32_t unused;
+    const uint32_t n_tiles = gen_count ? udiv_by(gen_rem + gen_count - 1u, pp.per_tile, pp.per_tile_magic, unused) + 1u : 0u;
+    const uint32_t runs_per_tile = ((uint32_t)pp.n_samples + RT_GEN_RUN - 1u) / RT_GEN_RUN;
+    const uint32_t n_units = n_tiles * runs_per_tile * 256u;           // fewer than the refill's paths plus two tiles' worth
+    // the grid is sized for the chip, not for the pool: a workgroup strides over the units
+    for (uint32_t u = blockIdx.x * RT_BLOCK + threadIdx.x; u < n_units; u += gridDim.x * RT_BLOCK) {
+        const uint32_t p = u & 255u, run_index = u >> 8;
+        const uint32_t tile_rel = run_index / runs_per_tile, run = run_index - tile_rel * runs_per_tile;
+        const uint32_t tile = ctl->gen_tile + tile_rel;
+        uint32_t tx_;
+        const int ty = (int)udiv_by(tile, (uint32_t)pp.tiles_x, pp.tiles_x_magic, tx_), tx = (int)tx_;
         const int wave = p >> 6, lane = p & 63;
         const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
         const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-        // the region that takes new path j: the last one whose share starts at or before j -- searched for the thread's
-        // first path, stepped to for its later ones (j only grows, by less than a few regions' shares at a time)
-        if (reg == RT_REGIONS_MAX) {
-            uint32_t lo = 0, hi = regions - 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
-            }
-            reg = lo;
-        } else {
-            while (reg + 1 < regions && new_before[reg + 1] <= j) reg++;
-        }
-        const uint32_t pos = (reg << log2_region_cap) + ctl->gen_base[reg] + (j - new_before[reg]);
-        const int sample = pp.first_sample + (int)s;
-        int depth = pp.max_depth;
+        const bool inside = x < pp.cam.width && y < pp.cam.height;
+        const int pixel = inside ? y * pp.cam.width + x : 0;
+        uint32_t reg = RT_REGIONS_MAX;       // the region that took this thread's last path; none yet
+        uint32_t batch_of_dir = 0xFFFFFFFFu;
         v3 dir = mk3(0.0f, 0.0f, 1.0f);
-        int pixel = 0;
-        if (x < pp.cam.width && y < pp.cam.height) {
-            pixel = y * pp.cam.width + x;
-            uint32_t w0, w1, w2, w3;
-            philox((uint32_t)pixel, (uint32_t)(sample / pp.batch), 0u, 1u, pp.key0, pp.key1, w0, w1, w2, w3);
-            dir = primary_dir(pp.cam, x, y, u01(w0), u01(w1));
-            if (depth == 0) {
-                // `while (depth--)` never runs: the path adds nothing (raytrace.cu:213, 243)
-                float* slot = pp.slots + ((size_t)s * (size_t)pp.n_pixel + (size_t)pixel) * 3;
-                slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
-                depth = -1;
-                n_paths++;
+        const uint32_t s_end = min((uint32_t)pp.n_samples, (run + 1u) * RT_GEN_RUN);
+        for (uint32_t s = run * RT_GEN_RUN; s < s_end; s++) {
+            const uint32_t along = tile_rel * pp.per_tile + s * 256u + p;
+            if (along < gen_rem) continue;                   // before the refill's first id (its first tile only)
+            const uint32_t j = along - gen_rem;
+            if (j >= gen_count) break;                       // past its last id (its last tile only)
+            // the region that takes new path j: the last one whose share starts at or before j -- searched for the
+            // thread's first path, stepped to for its later ones (j grows by 256 at a time)
+            if (reg == RT_REGIONS_MAX) {
+                uint32_t lo = 0, hi = regions - 1;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
+                }
+                reg = lo;
+            } else {
+                while (reg + 1 < regions && new_before[reg + 1] <= j) reg++;
             }
-        } else {
-            depth = -1;
+            const uint32_t pos = (reg << log2_region_cap) + ctl->gen_base[reg] + (j - new_before[reg]);
+            int depth = pp.max_depth;
+            if (inside) {
+                const int sample = pp.first_sample + (int)s;
+                uint32_t in_batch;
+                const uint32_t batch_index = udiv_by((uint32_t)sample, (uint32_t)pp.batch, pp.batch_magic, in_batch);
+                if (batch_index != batch_of_dir) {
+                    uint32_t w0, w1, w2, w3;
+                    philox((uint32_t)pixel, batch_index, 0u, 1u, pp.key0, pp.key1, w0, w1, w2, w3);
+                    dir = primary_dir(pp.cam, x, y, u01(w0), u01(w1));
+                    batch_of_dir = batch_index;
+                }
+                if (depth == 0) {
+                    // `while (depth--)` never runs: the path adds nothing (raytrace.cu:213, 243)
+                    float* slot = pp.slots + ((size_t)s * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                    slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
+                    depth = -1;
+                    n_paths++;
+                }
+            } else {
+                depth = -1;
+            }
+            pools.p0[nxt][pos] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth > 0 ? ((uint32_t)pixel | RT_FRESH_PATH) : 0xFFFFFFFFu));
         }
-        pools.p0[nxt][pos] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth > 0 ? ((uint32_t)pixel | RT_FRESH_PATH) : 0xFFFFFFFFu));
     }
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
 }
@@ -611,8 +630,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
             float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
             int sample;
             if (word & RT_FRESH_PATH) {
-                const uint32_t rem = ctl->gen_rem + ctl->gen_prefix[reg] + (local - ctl->gen_base[reg]);
-                sample = pp.first_sample + (int)((rem % ((uint32_t)pp.n_samples * 256u)) >> 8);
+                uint32_t in_tile;
+                (void)udiv_by(ctl->gen_rem + ctl->gen_prefix[reg] + (local - ctl->gen_base[reg]), pp.per_tile, pp.per_tile_magic, in_tile);
+                sample = pp.first_sample + (int)(in_tile >> 8);
             } else {
                 b = pool_load(&pools.p1[cur][i]);
                 c = pool_load(&pools.p2[cur][i]);
@@ -1131,6 +1151,14 @@ static void timing_collect(rt_context* ctx) {
 #define RT_SLOTS_MAX_BYTES ((size_t)64 << 30)
 #define RT_CTL_RING 4
 #define RT_CTL_GROUP 4
+static uint32_t magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
+static void set_divisors(PathParams& pp) {
+    pp.per_tile = (uint32_t)pp.n_samples * 256u;
+    pp.per_tile_magic = magic_of(pp.per_tile);
+    pp.tiles_x_magic = magic_of((uint32_t)pp.tiles_x);
+    pp.batch_magic = magic_of((uint32_t)pp.batch);
+}
+
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
 // samples are split between the pipelines; every path writes its own slot, so the split changes no result.
 static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
@@ -1206,6 +1234,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         R.pp.first_sample = pp.first_sample + first;
         R.pp.n_samples = last - first;
         R.pp.slots = pp.slots + (size_t)first * (size_t)pp.n_pixel * 3;
+        set_divisors(R.pp);
         R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_samples;
         R.cur = 0;
         for (int& c : R.snap_cur) c = 0;
@@ -1272,10 +1301,10 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
 }
 
 // Which node records the closest-hit kernel should keep in LDS depends on the scene AND the camera: the records rays
-// enter most.  The static numbering (largest boxes first) is a guess; this measures.  One sample per pixel is traced
-// with the counting build of the megakernel -- same rays, same walk as the frame's -- into a histogram of visits over
+// enter most.  The static numbering (largest boxes first) is a guess; this measures.  One sample per pixel of a reduced
+// frame is traced with the counting build of the megakernel -- same rays, same walk as the frame's -- into a histogram of visits over
 // the first RT_HIST_NODES records, and those records are renumbered by falling count (ties: old order).  Node numbers
-// are only addresses: no result changes.  Costs one sample per pixel (a few milliseconds) and a stream
+// are only addresses: no result changes.  Costs about ten milliseconds and a stream
 // synchronisation, so it runs once per scene and camera, and only for calls of at least RT_TUNE_MIN_SPP samples.
 #define RT_TUNE_MIN_SPP 64
 static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
@@ -1292,6 +1321,13 @@ static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
     pp.n_samples = 1;
     pp.chunk = 1;
     pp.n_chunks = 1;
+    // the same view at a quarter of the resolution each way: a sixteenth of the paths tells the visit counts of a few
+    // thousand records apart just as well (the counting megakernel is slow: a full-resolution sample cost 190 ms)
+    pp.cam.width = std::max(16, pp.cam.width / 4);
+    pp.cam.height = std::max(16, pp.cam.height / 4);
+    pp.n_pixel = pp.cam.width * pp.cam.height;
+    pp.tiles_x = (pp.cam.width + 15) / 16;
+    pp.tiles_y = (pp.cam.height + 15) / 16;
     pp.counters = (unsigned long long*)(base + hist_bytes);      // the calibration's rays are not the frame's: counted apart and dropped
     pp.hist = d_hist;
     const long long nblocks = (long long)pp.tiles_x * pp.tiles_y;
@@ -1381,6 +1417,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.lds_slots = lds_slots(ctx);
     pp.sort_rays = ctx->opt_wf_sort;
     pp.hist = nullptr;
+    pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
     const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
     if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
         pp.first_sample = first_sample;
