@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
     ap.add_argument("--wf-lanes", type=int, default=0)
+    ap.add_argument("--share-primary", type=int, default=-1, help="1/0: one closest-hit walk per pixel and semantic batch / one per sample (default: library default)")
     ap.add_argument("--hot-tune", type=int, default=-1, help="1/0: number the LDS-resident node records by measured visits (default: library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the scene tree on the device (RT_OPT_GPU_BVH) instead of re-packing upstream's trees")
     ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
@@ -203,6 +204,9 @@ def main():
         ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
     if args.hot_tune >= 0:
         ctx.set_option(capi.OPT_HOT_TUNE, args.hot_tune)
+    # the headline counts closest-hit queries as upstream executes them, so it walks every one (see `shared_primary` on the line)
+    ctx.set_option(capi.OPT_SHARE_PRIMARY, args.share_primary if args.share_primary >= 0 else 0)
+    wavefront_mode = args.mode in (None, "", "wavefront")
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
     npix = cfg.width * cfg.height
@@ -309,38 +313,65 @@ def main():
     bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"] + 100.0 * mix["shaded_per_ray"] + 16.0 * mix["tex_per_ray"]
     ctx.set_option(capi.OPT_COUNTERS, 0)
 
+    def timed_region(first_step, n_steps):
+        """n_steps steps bracketed by barrier + synchronize on both sides; max-over-ranks time, whole-job counts."""
+        ctx.set_option(capi.OPT_TIMING, 1)
+        ctx.reset_counters()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            run_step(first_step + k, events[k])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        cnt = ctx.counters()
+        tim = ctx.timing()
+        rays, paths, walks = float(cnt[capi.CNT_RAYS]), float(cnt[capi.CNT_PATHS]), float(cnt[capi.CNT_WALKS])
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            r = torch.tensor([rays, paths, walks], dtype=torch.float64, device=stat_device)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rays, paths, walks = (float(x) for x in r.tolist())
+        return {"elapsed": elapsed, "cnt": cnt, "tim": tim, "rays": rays, "paths": paths, "walks": walks,
+                "step_ms": [a.elapsed_time(b) for a, b in events]}
+
+    # ---- the same frame with the library's shared first walk (RT_OPT_SHARE_PRIMARY), timed the same way ----
+    # `value` below is measured with every one of upstream's closest-hit queries walked on its own.  The samples of a semantic
+    # batch start with one and the same primary ray, and the library by default walks it once for all of them: the image is
+    # the same bit for bit and the frame is faster, but fewer walks are executed than rays are counted, so that rate is
+    # reported beside the headline, not as it.
+    shared_line = None
+    if wavefront_mode and args.share_primary < 0:
+        ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+        run_step(0)
+        sh = timed_region(1, args.steps)
+        ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        accum.zero_()
+        sh_ms = sh["elapsed"] * 1e3 / max(1, args.steps)
+        shared_line = {"option": "RT_OPT_SHARE_PRIMARY = 1 (library default): one closest-hit walk per pixel and semantic batch, same image bit for bit",
+                       "ms_per_step": round(sh_ms, 3),
+                       "seconds_per_frame": round(sh_ms * 1e-3 * frame_spp / (spp * world), 3),
+                       "upstream_rays_mrays_per_s": round(sh["rays"] / sh["elapsed"] / 1e6, 2),
+                       "walks_executed_mrays_per_s": round(sh["walks"] / sh["elapsed"] / 1e6, 2),
+                       "walks_per_upstream_ray": round(sh["walks"] / max(1.0, sh["rays"]), 4),
+                       "kernel_share": {"extend_ms": round(sh["tim"]["extend_ms"], 2), "extend_launches": sh["tim"]["extend_launches"],
+                                        "shade_ms": round(sh["tim"]["shade_ms"], 2), "shade_launches": sh["tim"]["shade_launches"],
+                                        "wall_ms": round(sh["elapsed"] * 1e3, 2)}}
+
     # ---- warmup ----
     for s in range(args.warmup):
         run_step(s)
     torch.cuda.synchronize()
-    ctx.set_option(capi.OPT_TIMING, 1)
-    ctx.reset_counters()
 
     # ---- timed region ----
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run_step(args.warmup + k, events[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    cnt = ctx.counters()
-    tim = ctx.timing()
-    rays = float(cnt[capi.CNT_RAYS])
-    paths = float(cnt[capi.CNT_PATHS])
-    step_ms = [a.elapsed_time(b) for a, b in events]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays, paths], dtype=torch.float64, device=stat_device)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays, paths = float(r[0].item()), float(r[1].item())
+    main = timed_region(args.warmup, args.steps)
+    elapsed, cnt, tim, rays, paths, step_ms = main["elapsed"], main["cnt"], main["tim"], main["rays"], main["paths"], main["step_ms"]
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -389,7 +420,9 @@ def main():
                        "mode": args.mode or "library default (wavefront)",
                        "tree": "built on the device (LBVH, RT_OPT_GPU_BVH)" if args.gpu_bvh else "upstream's median-split trees, re-packed",
                        "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU",
-                       "reduce": reduce_via},
+                       "reduce": reduce_via,
+                       "first_walk": "shared by the samples of a semantic batch (RT_OPT_SHARE_PRIMARY = 1)" if args.share_primary == 1
+                                     else "one per sample, as upstream executes it (RT_OPT_SHARE_PRIMARY = 0)"},
             "seconds_per_frame": round(ms_per_step * 1e-3 * frame_spp / (spp * world), 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "gpu_ms_per_step_events": round(float(np.mean(step_ms)), 3) if step_ms else None,
@@ -405,6 +438,8 @@ def main():
                          "demand_note": "32*box_tests + 36*triangle_tests per ray: requested of LDS/L1/L2/Infinity Cache, not of HBM",
                          "counter_passes": pmc_source},
             "binding": binding,
+            "shared_primary": shared_line,
+            "walks_per_upstream_ray": round(main["walks"] / max(1.0, rays), 4),
             "kernel_share": {"extend_ms": round(tim["extend_ms"], 2), "extend_launches": tim["extend_launches"],
                              "shade_ms": round(tim["shade_ms"], 2), "shade_launches": tim["shade_launches"],
                              "path_ms": round(tim["path_ms"], 2), "wall_ms": round(elapsed * 1e3, 2)},

@@ -96,7 +96,7 @@ typedef struct rt_context rt_context;
 
 /* counters returned by rt_get_counters */
 enum {
-    RT_CNT_RAYS = 0,          /* closest-hit queries (one per depth-loop iteration, cuda/raytrace.cu:213-219) */
+    RT_CNT_RAYS = 0,          /* closest-hit queries as upstream runs them: one per sample and depth-loop iteration (cuda/raytrace.cu:213-219) */
     RT_CNT_BOX_TESTS,         /* AABB slab tests */
     RT_CNT_TRI_TESTS,         /* Moller-Trumbore tests */
     RT_CNT_SHADED,            /* hits that reached triangle_interpolate */
@@ -119,6 +119,7 @@ enum {
     RT_CNT_TAIL_IDLE_TICKS,   /* ... of which behind waves that ended before the launch's last one */
     RT_CNT_CYC_CLAIM,         /* closest-hit waves: clock cycles spent waiting for chunk claims (inside the refill cycles), and */
     RT_CNT_CLAIMS,            /* the number of claims */
+    RT_CNT_WALKS,             /* closest-hit walks actually run: equals RT_CNT_RAYS unless samples share their first walk (RT_OPT_SHARE_PRIMARY) */
     RT_CNT_COUNT = 24
 };
 
@@ -153,6 +154,12 @@ enum {
                                  those records are renumbered by falling count, so that the records the closest-hit kernel keeps in LDS
                                  (RT_OPT_HOT_NODES) are the ones this view enters most; 0 = static order (largest boxes first).
                                  Scheduling only: node numbers are addresses */
+    RT_OPT_SHARE_PRIMARY = 19, /* wavefront: 1 (default) = the samples of a semantic batch, which upstream starts with one and the same jittered
+                                 primary ray (cuda/raytrace.cu:210, its README's "Hints"), share ONE closest-hit walk for it: a new pool entry
+                                 stands for a pixel's run of samples of one batch, is walked once, and every sample is shaded from that hit with
+                                 its own draws.  Same image bit for bit, RT_CNT_RAYS unchanged (rays as upstream counts them), RT_CNT_WALKS and
+                                 the box/triangle test counts drop.  0 = one walk per sample, as upstream executes it.  Off by itself when the
+                                 batch is longer than an eighth of a pool region */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (Morton-code LBVH, rocPRIM sorts): a load-time option for large scenes, replacing

@@ -31,7 +31,7 @@ MATERIAL_DTYPE = np.dtype(
 
 MAT_NONE, MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_REFRACTIVE, MAT_REFLECTIVE = range(6)
 
-CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK, CNT_WAVE_NODE_TRIPS, CNT_WAVE_LEAF_TRIPS, CNT_NODE_VISITS, CNT_HOT_VISITS, CNT_CYC_REFILL, CNT_CYC_NODE, CNT_CYC_LEAF, CNT_CYC_WAVE, CNT_WAVE_SPAN_TICKS, CNT_WAVES, CNT_MAX_RAY_VISITS, CNT_NONFINITE_RAYS, CNT_LAUNCH_SLOT_TICKS, CNT_TAIL_IDLE_TICKS, CNT_CYC_CLAIM, CNT_CLAIMS = range(23)
+CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SHADED, CNT_TEX_FETCHES, CNT_PATHS, CNT_MAX_STACK, CNT_WAVE_NODE_TRIPS, CNT_WAVE_LEAF_TRIPS, CNT_NODE_VISITS, CNT_HOT_VISITS, CNT_CYC_REFILL, CNT_CYC_NODE, CNT_CYC_LEAF, CNT_CYC_WAVE, CNT_WAVE_SPAN_TICKS, CNT_WAVES, CNT_MAX_RAY_VISITS, CNT_NONFINITE_RAYS, CNT_LAUNCH_SLOT_TICKS, CNT_TAIL_IDLE_TICKS, CNT_CYC_CLAIM, CNT_CLAIMS, CNT_WALKS = range(24)
 CNT_COUNT = 24
 OPT_COUNTERS, OPT_XCD_REMAP, OPT_CHUNK, OPT_PASS, OPT_LDS_SLOTS, OPT_MODE, OPT_WF_CAPACITY_LOG2, OPT_WF_RUN, OPT_WF_BURST = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_TIMING = 11
@@ -43,6 +43,7 @@ OPT_WF_BLOCK = 15
 OPT_WF_LANES = 16
 OPT_GPU_BVH = 17
 OPT_HOT_TUNE = 18
+OPT_SHARE_PRIMARY = 19
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 GROUP_ID_BYTES = 128

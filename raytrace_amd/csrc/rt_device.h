@@ -43,9 +43,22 @@ struct PathParams {
     int sort_rays;                        // unused (the compaction no longer orders by direction octant)
     uint32_t* hist;                       // calibration pass only: per-node visit counts (see TravCounters), else null
     // wavefront: divisors the refill and the shading kernel divide path numbers by, with floor(2^32 / divisor) beside them
-    uint32_t per_tile, per_tile_magic;    // paths of one 16x16 tile in this pass = n_samples * 256
+    uint32_t per_tile, per_tile_magic;    // pool entries one 16x16 tile starts in this pass = n_runs * 256
     uint32_t tiles_x_magic, batch_magic;
+    // wavefront: a new pool entry stands for a RUN of samples of one pixel that share their primary ray and therefore their
+    // first hit (cuda/raytrace.cu:210: every sample of a semantic batch starts with the batch's one jittered ray): run k of
+    // a pass covers the samples of [(run_base + k) * run_len, (run_base + k + 1) * run_len) that lie in the pass.
+    // run_len = the semantic batch (one closest-hit query per pixel and batch), or 1 (one per sample, as upstream runs it).
+    int run_len, run_base, n_runs;
+    uint32_t run_len_magic;
 };
+
+// samples [lo, hi) of run k of the pass (see PathParams)
+__device__ __forceinline__ void run_samples(const PathParams& pp, uint32_t k, int& lo, int& hi) {
+    const int a = (pp.run_base + (int)k) * pp.run_len, b = a + pp.run_len, end = pp.first_sample + pp.n_samples;
+    lo = a > pp.first_sample ? a : pp.first_sample;
+    hi = b < end ? b : end;
+}
 
 // x / d for a divisor the whole launch shares, with m = floor(2^32 / d) from the host: the estimate mulhi(x, m) is the
 // quotient or one below it (two corrections allowed for), which costs a multiply instead of the ~35 instructions of a
@@ -444,38 +457,60 @@ struct ShadeConst {
     uint32_t k0, k1;
 };
 
+// What the samples of one semantic batch share at their first hit (they share the primary ray, cuda/raytrace.cu:210):
+// everything triangle_interpolate computes (cuda/raytrace.cu:80-96) and the hit point.
+struct HitPrep {
+    bool hit;
+    v3 rd, point, normal, hit_color;
+    int mtype, textured;
+    float optical_density, metal_fuzz;
+};
+
+__device__ __forceinline__ void prepare_hit(const SceneDev& sc, const RayD& ray, const Hit& h, HitPrep& q) {
+    q.hit = h.tri != REF_NONE;
+    q.textured = 0;
+    q.mtype = RT_MAT_NONE;
+    q.optical_density = 1.0f; q.metal_fuzz = 0.0f;
+    q.rd = mk3(ray.dx, ray.dy, ray.dz);
+    q.point = q.normal = q.hit_color = mk3(0.0f, 0.0f, 0.0f);
+    if (!q.hit) return;
+    // ---- triangle_interpolate, raytrace.cu:80-96 ----
+    const float4* sq = reinterpret_cast<const float4*>(sc.shade + h.tri);
+    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
+    const float u = h.u, v = h.v;
+    const float w = 1.0f - u - v;
+    const v3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+    q.normal = vnormalize(vadd(vadd(vscale(n0, w), vscale(n1, u)), vscale(n2, v)));
+    const int mat_id = __float_as_int(s3.w);
+    const float4* mq = reinterpret_cast<const float4*>(sc.mats + mat_id);
+    const float4 m0 = mq[0], m1 = mq[1];
+    q.mtype = __float_as_int(m0.x);
+    q.optical_density = m1.x; q.metal_fuzz = m1.y;
+    const int mtex = __float_as_int(m1.z);
+    if (mtex < 0) {
+        q.hit_color = mk3(m0.y, m0.z, m0.w);
+    } else {
+        const float tcx = w * s2.y + u * s2.w + v * s3.y;
+        const float tcy = w * s2.z + u * s3.x + v * s3.z;
+        q.textured = 1;
+        q.hit_color = tex_fetch(sc, mtex, tcx, tcy);
+    }
+    q.point = vadd(mk3(ray.ox, ray.oy, ray.oz), vscale(q.rd, h.t));   // primitives.cuh:17-19
+}
+
+// The rest of the iteration for ONE sample: miss / light / roulette / scatter with that sample's draws.  `ray` is written
+// only when the path goes on.  Counts are per sample (what upstream executes per sample), whoever shared the preparation.
 template <bool COUNT>
-__device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& k, RayD& ray, const Hit& h, uint32_t pixel,
-                                          uint32_t sample, uint32_t bounce, v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
-    if (h.tri == REF_NONE) {
+__device__ __forceinline__ bool scatter_hit(const HitPrep& q, const ShadeConst& k, RayD& ray, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                            v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
+    if (!q.hit) {
         color = vmul(color, k.ambient); return true;      // raytrace.cu:220-223
     } else {
-        if (COUNT) n_shaded++;
-        // ---- triangle_interpolate, raytrace.cu:80-96 ----
-        const float4* sq = reinterpret_cast<const float4*>(sc.shade + h.tri);
-        const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
-        const float u = h.u, v = h.v;
-        const float w = 1.0f - u - v;
-        const v3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-        const v3 normal = vnormalize(vadd(vadd(vscale(n0, w), vscale(n1, u)), vscale(n2, v)));
-        const int mat_id = __float_as_int(s3.w);
-        const float4* mq = reinterpret_cast<const float4*>(sc.mats + mat_id);
-        const float4 m0 = mq[0], m1 = mq[1];
-        const int mtype = __float_as_int(m0.x);
-        const float optical_density = m1.x, metal_fuzz = m1.y;
-        const int mtex = __float_as_int(m1.z);
-        v3 hit_color;
-        if (mtex < 0) {
-            hit_color = mk3(m0.y, m0.z, m0.w);
-        } else {
-            const float tcx = w * s2.y + u * s2.w + v * s3.y;
-            const float tcy = w * s2.z + u * s3.x + v * s3.z;
-            if (COUNT) n_tex++;
-            hit_color = tex_fetch(sc, mtex, tcx, tcy);
-        }
-        const v3 rd = mk3(ray.dx, ray.dy, ray.dz);
-        const v3 point = vadd(mk3(ray.ox, ray.oy, ray.oz), vscale(rd, h.t));   // primitives.cuh:17-19
-            uint32_t w_rr, w_dec, w2_, w3_;
+        if (COUNT) { n_shaded++; n_tex += (uint32_t)q.textured; }
+        const v3 normal = q.normal, hit_color = q.hit_color, rd = q.rd, point = q.point;
+        const int mtype = q.mtype;
+        const float optical_density = q.optical_density, metal_fuzz = q.metal_fuzz;
+        uint32_t w_rr, w_dec, w2_, w3_;
         philox((uint32_t)pixel, (uint32_t)sample, bounce * 65536u, 0u, k.k0, k.k1, w_rr, w_dec, w2_, w3_);
         const float decision = u01(w_dec);
         if (mtype == RT_MAT_LIGHT) {
@@ -550,6 +585,14 @@ __device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& 
         }
     }
     return false;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& k, RayD& ray, const Hit& h, uint32_t pixel,
+                                          uint32_t sample, uint32_t bounce, v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
+    HitPrep q;
+    prepare_hit(sc, ray, h, q);
+    return scatter_hit<COUNT>(q, k, ray, pixel, sample, bounce, color, n_shaded, n_tex);
 }
 
 #endif

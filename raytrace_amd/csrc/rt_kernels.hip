@@ -134,6 +134,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     }
 
     wave_add(pp.counters + RT_CNT_RAYS, n_rays);
+    wave_add(pp.counters + RT_CNT_WALKS, n_rays);
     wave_add(pp.counters + RT_CNT_PATHS, n_paths);
     if (COUNT) {
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
@@ -228,7 +229,7 @@ static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads 
 // against the paths not yet started), hands out the new path ids region after region, and lays out the closest-hit
 // launch's view of the pool.
 __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t regions, uint32_t region_cap,
-                                                                 uint32_t per_tile, unsigned long long* counters) {
+                                                                 uint32_t per_tile, uint32_t entry_yield, unsigned long long* counters) {
     __shared__ uint32_t scan[RT_REGIONS_MAX];
     const uint32_t r = threadIdx.x;
     if (r == 0 && ctl->n_worked) {
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         atomicAdd(&counters[RT_CNT_TAIL_IDLE_TICKS], ctl->t_last * ctl->n_worked - ctl->t_end_sum);
     }
     const uint32_t have = r < regions ? ctl->count[nxt][r * RT_QUEUE_STRIDE] : 0u;
-    const uint32_t room = r < regions ? region_cap - have : 0u;
+    // a new entry takes `entry_yield` lanes of the shading launch and may leave as many survivors behind (one per sample
+    // of its run), all in this region of the other pool: only as many entries are started as the region has room for that
+    const uint32_t room = r < regions ? (region_cap - have) / entry_yield : 0u;
     // exclusive prefix of the rooms: regions are filled in order until the paths run out
     auto exclusive = [&](uint32_t v) {
         scan[r] = v;
@@ -323,12 +326,12 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
     // the refill's ids, counted from the start of its first tile: [gen_rem, gen_rem + gen_count); the tiles they touch
     uint32_t unused;
     const uint32_t n_tiles = gen_count ? udiv_by(gen_rem + gen_count - 1u, pp.per_tile, pp.per_tile_magic, unused) + 1u : 0u;
-    const uint32_t runs_per_tile = ((uint32_t)pp.n_samples + RT_GEN_RUN - 1u) / RT_GEN_RUN;
-    const uint32_t n_units = n_tiles * runs_per_tile * 256u;           // fewer than the refill's paths plus two tiles' worth
+    const uint32_t chunks_per_tile = ((uint32_t)pp.n_runs + RT_GEN_RUN - 1u) / RT_GEN_RUN;
+    const uint32_t n_units = n_tiles * chunks_per_tile * 256u;         // fewer than the refill's entries plus two tiles' worth
     // the grid is sized for the chip, not for the pool: a workgroup strides over the units
     for (uint32_t u = blockIdx.x * RT_BLOCK + threadIdx.x; u < n_units; u += gridDim.x * RT_BLOCK) {
-        const uint32_t p = u & 255u, run_index = u >> 8;
-        const uint32_t tile_rel = run_index / runs_per_tile, run = run_index - tile_rel * runs_per_tile;
+        const uint32_t p = u & 255u, chunk_index = u >> 8;
+        const uint32_t tile_rel = chunk_index / chunks_per_tile, chunk = chunk_index - tile_rel * chunks_per_tile;
         const uint32_t tile = ctl->gen_tile + tile_rel;
         uint32_t tx_;
         const int ty = (int)udiv_by(tile, (uint32_t)pp.tiles_x, pp.tiles_x_magic, tx_), tx = (int)tx_;
@@ -337,17 +340,17 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
         const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
         const bool inside = x < pp.cam.width && y < pp.cam.height;
         const int pixel = inside ? y * pp.cam.width + x : 0;
-        uint32_t reg = RT_REGIONS_MAX;       // the region that took this thread's last path; none yet
+        uint32_t reg = RT_REGIONS_MAX;       // the region that took this thread's last entry; none yet
         uint32_t batch_of_dir = 0xFFFFFFFFu;
         v3 dir = mk3(0.0f, 0.0f, 1.0f);
-        const uint32_t s_end = min((uint32_t)pp.n_samples, (run + 1u) * RT_GEN_RUN);
-        for (uint32_t s = run * RT_GEN_RUN; s < s_end; s++) {
-            const uint32_t along = tile_rel * pp.per_tile + s * 256u + p;
+        const uint32_t k_end = min((uint32_t)pp.n_runs, (chunk + 1u) * RT_GEN_RUN);
+        for (uint32_t k = chunk * RT_GEN_RUN; k < k_end; k++) {
+            const uint32_t along = tile_rel * pp.per_tile + k * 256u + p;
             if (along < gen_rem) continue;                   // before the refill's first id (its first tile only)
             const uint32_t j = along - gen_rem;
             if (j >= gen_count) break;                       // past its last id (its last tile only)
-            // the region that takes new path j: the last one whose share starts at or before j -- searched for the
-            // thread's first path, stepped to for its later ones (j grows by 256 at a time)
+            // the region that takes new entry j: the last one whose share starts at or before j -- searched for the
+            // thread's first entry, stepped to for its later ones (j grows by 256 at a time)
             if (reg == RT_REGIONS_MAX) {
                 uint32_t lo = 0, hi = regions - 1;
                 while (lo < hi) {
@@ -361,9 +364,10 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
             const uint32_t pos = (reg << log2_region_cap) + ctl->gen_base[reg] + (j - new_before[reg]);
             int depth = pp.max_depth;
             if (inside) {
-                const int sample = pp.first_sample + (int)s;
+                int s_lo, s_hi;
+                run_samples(pp, k, s_lo, s_hi);              // never across a batch boundary: one jitter serves the run
                 uint32_t in_batch;
-                const uint32_t batch_index = udiv_by((uint32_t)sample, (uint32_t)pp.batch, pp.batch_magic, in_batch);
+                const uint32_t batch_index = udiv_by((uint32_t)s_lo, (uint32_t)pp.batch, pp.batch_magic, in_batch);
                 if (batch_index != batch_of_dir) {
                     uint32_t w0, w1, w2, w3;
                     philox((uint32_t)pixel, batch_index, 0u, 1u, pp.key0, pp.key1, w0, w1, w2, w3);
@@ -371,11 +375,13 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
                     batch_of_dir = batch_index;
                 }
                 if (depth == 0) {
-                    // `while (depth--)` never runs: the path adds nothing (raytrace.cu:213, 243)
-                    float* slot = pp.slots + ((size_t)s * (size_t)pp.n_pixel + (size_t)pixel) * 3;
-                    slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
+                    // `while (depth--)` never runs: the paths add nothing (raytrace.cu:213, 243)
+                    for (int smp = s_lo; smp < s_hi; smp++) {
+                        float* slot = pp.slots + ((size_t)(smp - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                        slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
+                    }
                     depth = -1;
-                    n_paths++;
+                    n_paths += (uint32_t)(s_hi - s_lo);
                 }
             } else {
                 depth = -1;
@@ -598,12 +604,16 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     }
 }
 
-// Shading and queue compaction.  Workgroup b reads 256 consecutive entries of region (b mod regions) of pool `cur` --
-// workgroups that run at the same time read different regions -- and every wave files its survivors at the front of the
-// same region of the other pool: 64-bit ballot, lane prefix count, ONE returning atomic per wave on that region's own
-// counter.  No LDS, no barrier.  (A counter shared by the whole chip was the bottleneck of two earlier designs: a
-// returning atomic on one word sustains ~90 per microsecond, and the barriers around a per-workgroup claim stalled
-// 1024-lane workgroups as a whole.)
+// Shading and queue compaction.  Workgroup b works on region (b mod regions) of pool `cur` -- workgroups that run at the
+// same time read different regions -- one lane per (entry, sample): a continuing path is one lane, a NEW entry (a pixel's
+// run of samples that share their primary ray and therefore its hit) as many lanes as the run is long, next to each
+// other, each shading the same hit with its own sample's draws.  The lanes of a run read the same pool and shading
+// records (one cache line serves them), so the walk and its HBM traffic are spent once per run while the per-sample
+// arithmetic stays what it is.  The planner admitted only as many new entries as leave `lanes <= region_cap`.
+// Every wave files its survivors at the front of the same region of the other pool: 64-bit ballot, lane prefix count,
+// ONE returning atomic per wave on that region's own counter.  No LDS, no barrier.  (A counter shared by the whole chip
+// was the bottleneck of two earlier designs: a returning atomic on one word sustains ~90 per microsecond, and the
+// barriers around a per-workgroup claim stalled 1024-lane workgroups as a whole.)
 #ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256
 #endif
@@ -611,61 +621,71 @@ template <bool COUNT>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, uint32_t regions, uint32_t log2_region_cap,
                                                                   PathParams pp) {
     const uint32_t reg = blockIdx.x % regions, within = blockIdx.x / regions;
-    const uint32_t local = within * RT_SHADE_BLOCK + threadIdx.x;          // place inside the region
+    const uint32_t local = within * RT_SHADE_BLOCK + threadIdx.x;          // lane's place among the region's lanes
     const uint32_t live = ctl->count[cur][reg * RT_QUEUE_STRIDE];
-    if (within * RT_SHADE_BLOCK >= live) return;                             // nothing of this region is left for this workgroup
-    const uint32_t i = (reg << log2_region_cap) + local;
+    const uint32_t continuing = ctl->gen_base[reg];                          // the new entries lie behind the continuing ones
+    const uint32_t lanes = continuing + (live - continuing) * (uint32_t)pp.run_len;
+    if (within * RT_SHADE_BLOCK >= lanes) return;                            // nothing of this region is left for this workgroup
     const int nxt = cur ^ 1;
-    uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0;
+    uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0, n_walks = 0;
     bool survives = false;
     float4 o0, o1, o2;
-    if (local < live) {
+    if (local < lanes) {
+        uint32_t entry = local, nth = 0;                                     // pool entry of the region; sample of its run
+        if (local >= continuing) entry = continuing + udiv_by(local - continuing, (uint32_t)pp.run_len, pp.run_len_magic, nth);
+        const uint32_t i = (reg << log2_region_cap) + entry;
         const float4 a = pool_load(&pools.p0[cur][i]), hq = pool_load(&pools.hit[i]);
         const uint32_t word = __float_as_uint(a.w);
         if ((int)word >= 0) {                                        // -1: nothing was traced for this entry
             const int pixel = (int)(word & RT_PIXEL_MASK);
-            // a new path: origin, sample, throughput and depth are implied (its sample index follows from its place in the
-            // refill, as wf_generate_kernel counted it out); any other path: second and third record
+            // a new entry: origin, throughput and depth are implied, and which run of samples it is follows from its place
+            // in the refill, as wf_generate_kernel counted it out; any other path: second and third record
             float4 b = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], 0.0f);
             float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
-            int sample;
+            int sample, s_hi;
             if (word & RT_FRESH_PATH) {
                 uint32_t in_tile;
-                (void)udiv_by(ctl->gen_rem + ctl->gen_prefix[reg] + (local - ctl->gen_base[reg]), pp.per_tile, pp.per_tile_magic, in_tile);
-                sample = pp.first_sample + (int)(in_tile >> 8);
+                (void)udiv_by(ctl->gen_rem + ctl->gen_prefix[reg] + (entry - continuing), pp.per_tile, pp.per_tile_magic, in_tile);
+                int s_lo;
+                run_samples(pp, in_tile >> 8, s_lo, s_hi);
+                sample = s_lo + (int)nth;
             } else {
                 b = pool_load(&pools.p1[cur][i]);
                 c = pool_load(&pools.p2[cur][i]);
                 sample = __float_as_int(b.w);
+                s_hi = sample + 1;
             }
-            int depth = __float_as_int(c.w);
-            depth--;                                                 // the segment extend just traced (raytrace.cu:213)
-            n_rays = 1;
-            ShadeConst sk;
-            sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
-            sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
-            RayD ray;
-            ray.ox = b.x; ray.oy = b.y; ray.oz = b.z; ray.dx = a.x; ray.dy = a.y; ray.dz = a.z;
-            ray.ix = ray.iy = ray.iz = 0.0f;                         // shading never reads the inverses
-            Hit h;
-            h.t = hq.x; h.u = hq.y; h.v = hq.z; h.tri = __float_as_uint(hq.w);
-            v3 color = mk3(c.x, c.y, c.z);
-            const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);
-            bool finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
-            if (!finished && depth == 0) {
-                // the next `while (depth--)` test fails: out of depth, the path adds nothing (raytrace.cu:243)
-                finished = true;
-                color = mk3(0.0f, 0.0f, 0.0f);
-            }
-            if (finished) {
-                n_paths = 1;
-                float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
-                slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
-            } else {
-                survives = true;
-                o0 = make_float4(ray.dx, ray.dy, ray.dz, __int_as_float(pixel));
-                o1 = make_float4(ray.ox, ray.oy, ray.oz, __int_as_float(sample));
-                o2 = make_float4(color.x, color.y, color.z, __int_as_float(depth));
+            if (sample < s_hi) {                                     // a slice's last run may be shorter than the others
+                int depth = __float_as_int(c.w);
+                depth--;                                             // the segment extend just traced (raytrace.cu:213)
+                n_rays = 1;
+                n_walks = nth == 0 ? 1u : 0u;
+                ShadeConst sk;
+                sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
+                sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
+                RayD ray;
+                ray.ox = b.x; ray.oy = b.y; ray.oz = b.z; ray.dx = a.x; ray.dy = a.y; ray.dz = a.z;
+                ray.ix = ray.iy = ray.iz = 0.0f;                     // shading never reads the inverses
+                Hit h;
+                h.t = hq.x; h.u = hq.y; h.v = hq.z; h.tri = __float_as_uint(hq.w);
+                v3 color = mk3(c.x, c.y, c.z);
+                const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);
+                bool finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
+                if (!finished && depth == 0) {
+                    // the next `while (depth--)` test fails: out of depth, the path adds nothing (raytrace.cu:243)
+                    finished = true;
+                    color = mk3(0.0f, 0.0f, 0.0f);
+                }
+                if (finished) {
+                    n_paths = 1;
+                    float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                    slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
+                } else {
+                    survives = true;
+                    o0 = make_float4(ray.dx, ray.dy, ray.dz, __int_as_float(pixel));
+                    o1 = make_float4(ray.ox, ray.oy, ray.oz, __int_as_float(sample));
+                    o2 = make_float4(color.x, color.y, color.z, __int_as_float(depth));
+                }
             }
         }
     }
@@ -680,13 +700,16 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
         pool_store(&pools.p1[nxt][pos], o1);
         pool_store(&pools.p2[nxt][pos], o2);
     }
-    // finished paths and traced rays (one closest-hit query per live path): every wave adds its sums, spread over
-    // RT_CNT_SPREAD cache lines -- on one word the additions would queue up behind each other
-    const uint32_t fin = (uint32_t)__popcll(__ballot(n_paths != 0)), rays = (uint32_t)__popcll(__ballot(n_rays != 0));
+    // finished paths, rays as upstream counts them (one per sample and depth-loop iteration, cuda/raytrace.cu:213-219) and
+    // closest-hit walks actually run (one per entry): every wave adds its sums, spread over RT_CNT_SPREAD cache lines --
+    // on one word the additions would queue up behind each other
+    const uint32_t fin = (uint32_t)__popcll(__ballot(n_paths != 0)), rays = (uint32_t)__popcll(__ballot(n_rays != 0)),
+                   walks = (uint32_t)__popcll(__ballot(n_walks != 0));
     if (lane == 0) {
         unsigned long long* spread = pp.counters + RT_CNT_COUNT + ((blockIdx.x * (RT_SHADE_BLOCK / 64) + (threadIdx.x >> 6)) & (RT_CNT_SPREAD - 1u)) * RT_CNT_SPREAD_STRIDE;
         if (fin) atomicAdd(spread, (unsigned long long)fin);
         if (rays) atomicAdd(spread + 1, (unsigned long long)rays);
+        if (walks) atomicAdd(spread + 2, (unsigned long long)walks);
     }
     if (COUNT) {
         wave_add(pp.counters + RT_CNT_SHADED, n_shaded);
@@ -719,6 +742,7 @@ __global__ __launch_bounds__(RT_BLOCK) void closest_hit_kernel(SceneDev sc, int 
         if (v) v[i] = h.v;
     }
     wave_add(counters + RT_CNT_RAYS, n_r);
+    wave_add(counters + RT_CNT_WALKS, n_r);
     add_trav_counters(counters, tc);
 }
 
@@ -797,6 +821,7 @@ struct rt_context {
     int opt_hot_tune = 1;            // wavefront: number the node records by measured visits before a frame (one calibration sample per pixel)
     bool hot_dirty = true;           // scene or camera changed since the node numbering was last tuned
     void* d_tune = nullptr;          // calibration scratch: visit counts, throw-away counters, permutation, a copy of the candidate records
+    int opt_share_primary = 1;       // wavefront: one closest-hit query per pixel and semantic batch (its samples share the primary ray)
     int opt_gpu_bvh = 0;             // 1 = rt_upload_scene builds its own tree on the device instead of re-packing the caller's
     int opt_lds_slots = 11;          // stack levels kept in LDS (deeper ones spill to private memory)
     int opt_chunk = 8;               // samples one lane traces in a row
@@ -957,6 +982,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return RT_OK;
     case RT_OPT_GPU_BVH: ctx->opt_gpu_bvh = value ? 1 : 0; return RT_OK;
     case RT_OPT_HOT_TUNE: ctx->opt_hot_tune = value ? 1 : 0; return RT_OK;
+    case RT_OPT_SHARE_PRIMARY: ctx->opt_share_primary = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
@@ -1152,11 +1178,16 @@ static void timing_collect(rt_context* ctx) {
 #define RT_CTL_RING 4
 #define RT_CTL_GROUP 4
 static uint32_t magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
-static void set_divisors(PathParams& pp) {
-    pp.per_tile = (uint32_t)pp.n_samples * 256u;
+// How a pass's samples are cut into runs that share a primary ray, and the divisors that go with it (see PathParams).
+static void set_runs(PathParams& pp, int run_len) {
+    pp.run_len = run_len;
+    pp.run_base = pp.first_sample / run_len;
+    pp.n_runs = (pp.first_sample + pp.n_samples - 1) / run_len - pp.run_base + 1;
+    pp.per_tile = (uint32_t)pp.n_runs * 256u;
     pp.per_tile_magic = magic_of(pp.per_tile);
     pp.tiles_x_magic = magic_of((uint32_t)pp.tiles_x);
     pp.batch_magic = magic_of((uint32_t)pp.batch);
+    pp.run_len_magic = magic_of((uint32_t)run_len);
 }
 
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
@@ -1220,7 +1251,8 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     HIP_TRY(hipEventRecord(ctx->fork_ev, s));
     struct LaneRun {
         PathParams pp;
-        unsigned long long total;
+        unsigned long long total;       // pool entries the pass starts (runs of samples x pixels of whole tiles)
+        uint32_t entry_yield;           // survivors a new entry can leave at most
         int cur;
         int snap_cur[RT_CTL_RING];
         unsigned iter;
@@ -1234,8 +1266,12 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         R.pp.first_sample = pp.first_sample + first;
         R.pp.n_samples = last - first;
         R.pp.slots = pp.slots + (size_t)first * (size_t)pp.n_pixel * 3;
-        set_divisors(R.pp);
-        R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_samples;
+        // one closest-hit query per pixel and semantic batch, unless the option says one per sample or a run's survivors
+        // would take more than an eighth of a region
+        const int run_len = (ctx->opt_share_primary && pp.batch > 1 && (uint32_t)pp.batch <= (cap / regions) / 8u) ? pp.batch : 1;
+        set_runs(R.pp, run_len);
+        R.entry_yield = (uint32_t)run_len;      // the shading launch gives every new entry run_len lanes, whatever the slice cuts off
+        R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_runs;
         R.cur = 0;
         for (int& c : R.snap_cur) c = 0;
         R.iter = 0;
@@ -1261,7 +1297,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                 else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 timing_end(ctx, tk, ls);
             }
-            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, (uint32_t)R.pp.n_samples * 256u,
+            hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, R.pp.per_tile, R.entry_yield,
                                ctx->d_counters);
             hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, regions, log2_region_cap, R.pp);
             const int tke = timing_begin(ctx, 0, ls);
@@ -1418,6 +1454,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.sort_rays = ctx->opt_wf_sort;
     pp.hist = nullptr;
     pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
+    pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_len_magic = 0xFFFFFFFFu;
     const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
     if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
         pp.first_sample = first_sample;
@@ -1505,9 +1542,10 @@ int rt_get_counters(rt_context* ctx, uint64_t out[RT_CNT_COUNT]) {
     std::vector<uint64_t> all(RT_CNT_WORDS);
     HIP_TRY(hipMemcpy(all.data(), ctx->d_counters, RT_CNT_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     for (int k = 0; k < RT_CNT_COUNT; k++) out[k] = all[k];
-    for (uint32_t b = 0; b < RT_CNT_SPREAD; b++) {            // the shading kernel's share of these two, kept in RT_CNT_SPREAD places
+    for (uint32_t b = 0; b < RT_CNT_SPREAD; b++) {            // the shading kernel's share of these three, kept in RT_CNT_SPREAD places
         out[RT_CNT_PATHS] += all[RT_CNT_COUNT + b * RT_CNT_SPREAD_STRIDE];
         out[RT_CNT_RAYS] += all[RT_CNT_COUNT + b * RT_CNT_SPREAD_STRIDE + 1];
+        out[RT_CNT_WALKS] += all[RT_CNT_COUNT + b * RT_CNT_SPREAD_STRIDE + 2];
     }
     return RT_OK;
 }

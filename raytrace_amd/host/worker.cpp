@@ -85,6 +85,8 @@ Worker::Worker(const std::string& scene_file, const std::string& output_dir, int
             std::cerr << "Failed to set up the device: " << rt_last_error() << std::endl;
             std::exit(0);
         }
+        // RT_SHARE_PRIMARY=0: walk every sample's primary ray on its own, as upstream executes it (same picture, slower)
+        if (const char* share = std::getenv("RT_SHARE_PRIMARY")) rt_set_option(g.ctx, RT_OPT_SHARE_PRIMARY, std::atoi(share) != 0);
         if (rt_device_alloc(g.ctx, n_pixels_ * 3 * sizeof(float), reinterpret_cast<void**>(&g.accum)) != RT_OK) {
             std::cerr << "Failed to allocate device memory for buffer, error: " << rt_last_error() << std::endl;
             std::exit(0);

@@ -514,3 +514,52 @@ def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
     for k in (capi.CNT_RAYS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS, capi.CNT_NODE_VISITS):
         assert ca[k] == cb[k], k
     assert cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
+
+
+def _runs(first, n, batch):
+    """Semantic batches the samples [first, first + n) touch: one shared walk each."""
+    return (first + n - 1) // batch - first // batch + 1 if n > 0 else 0
+
+
+@pytest.mark.parametrize("name,kw,first,n,batch,cap,lanes,shared", [
+    ("material_box", dict(width=64, height=40, n_samples=16), 0, 16, 4, 11, 1, True),     # pool of 2048 entries: many refills
+    ("material_box", dict(width=33, height=17, n_samples=10), 0, 10, 4, 11, 1, True),     # partial tiles, partial last batch
+    ("material_box", dict(width=33, height=17, n_samples=16), 4, 7, 4, 12, 1, True),      # a later slice that ends inside a batch
+    ("material_box", dict(width=64, height=40, n_samples=16), 0, 16, 64, 11, 1, False),   # batch longer than an eighth of a region: not shared
+    ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 0, 8, 8, 14, 1, True),
+    ("formula1", dict(width=96, height=60, n_samples=16, detail=0.05, tex_size=64), 0, 16, 16, 22, 1, True),   # pool larger than the job
+    ("formula1", dict(width=96, height=60, n_samples=16, detail=0.05, tex_size=64), 0, 16, 4, 14, 2, True),    # two pipelines split the samples
+    ("room", dict(width=60, height=40, n_samples=8, detail=0.2, tex_size=64), 0, 8, 4, 13, 1, True),          # 16 bounces, camera inside
+    ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 0, 8, 1, 12, 1, False),      # batch of one: nothing to share
+])
+def test_shared_primary_walk_bit_exact(gpu_ctx, name, kw, first, n, batch, cap, lanes, shared):
+    """RT_OPT_SHARE_PRIMARY: the samples of a semantic batch start with one and the same primary ray
+    (cuda/raytrace.cu:210), so one closest-hit walk serves them all.  The image and every count upstream's execution
+    defines per sample stay what they were; the walks run are exactly the primaries saved fewer."""
+    p = Pair(gpu_ctx, getattr(scene, name)(**kw))
+    ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, batch), first, n)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, cap)
+    gpu_ctx.set_option(capi.OPT_WF_LANES, lanes)
+    gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+    try:
+        got, gcnt = p.gpu_render(first, n, batch)
+        again, _ = p.gpu_render(first, n, batch)
+    finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        gpu_ctx.set_option(capi.OPT_WF_LANES, 1)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert same_f32(again, ref)
+    npix = p.cfg.width * p.cfg.height
+    assert gcnt[capi.CNT_RAYS] == rcnt[0]
+    assert gcnt[capi.CNT_SHADED] == rcnt[3] and gcnt[capi.CNT_TEX_FETCHES] == rcnt[4]
+    assert gcnt[capi.CNT_PATHS] == npix * n
+    if shared and lanes == 1:
+        assert gcnt[capi.CNT_WALKS] == rcnt[0] - npix * n + npix * _runs(first, n, batch)
+        assert gcnt[capi.CNT_TRI_TESTS] < rcnt[2]
+    elif shared:
+        assert gcnt[capi.CNT_WALKS] < rcnt[0]            # how the pipelines cut the samples is theirs to choose
+    else:
+        assert gcnt[capi.CNT_WALKS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2]
