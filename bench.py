@@ -61,7 +61,7 @@ def source_hash():
 
 
 def workload_key(args, cfg):
-    return f"{args.scene}_{cfg.width}x{cfg.height}_detail{args.detail:g}_depth{cfg.max_depth}" + ("_gpubvh" if args.gpu_bvh else "")
+    return f"{args.scene}_{cfg.width}x{cfg.height}_detail{args.detail:g}_depth{cfg.max_depth}" + ("_gpubvh" if args.gpu_bvh else "") + ("_sharedwalk" if args.share_primary == 1 else "")
 
 
 def counter_passes(key):

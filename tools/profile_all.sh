@@ -4,16 +4,20 @@
 # Results under gpurun_out/<tag>/; tools/make_traffic.py <tag> <round> turns them into profiles/<round>/.
 set -e
 tag=$1; shift
+# bench.py by itself times the frame twice (every ray walked = its value; shared first walk beside it).  The trace and the
+# counter passes must see one kind of launch only: the headline's, unless the arguments choose.
+one="--share-primary 0"
+case " $* " in *" --share-primary "*) one="";; esac
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 400 python3 bench.py "$@" > $out/bench_default.json 2> $out/bench_default.log
 mkdir -p $out/trace
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/bench_under_rocprof.json 2> $out/trace/bench.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $one "$@" > $out/bench_under_rocprof.json 2> $out/trace/bench.err
 cp "$(find $out/trace -name '*kernel_stats.csv' | head -1)" $out/bench_kernel_stats.csv
 pmc() {   # <name> <counters>
     mkdir -p $out/pmc_$1
-    timeout -s KILL 500 rocprofv3 --pmc $2 --output-format csv -d $out/pmc_$1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "${@:3}" > $out/pmc_$1/bench.json 2> $out/pmc_$1/bench.err
+    timeout -s KILL 500 rocprofv3 --pmc $2 --output-format csv -d $out/pmc_$1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $one "${@:3}" > $out/pmc_$1/bench.json 2> $out/pmc_$1/bench.err
     python3 tools/pmc_summary.py $out/pmc_$1 > $out/pmc_$1.txt
 }
 pmc fetch "FETCH_SIZE" "$@"
