@@ -378,12 +378,14 @@ def main():
         mrays = rays / elapsed / 1e6
         my_rays = float(cnt[capi.CNT_RAYS])
         my_paths = float(cnt[capi.CNT_PATHS])
+        my_walks = float(cnt[capi.CNT_WALKS])        # closest-hit walks run = rays, unless the first walk of a batch is shared
         demand_bytes_per_ray = 32.0 * mix["box_tests_per_ray"] + 36.0 * mix["tri_tests_per_ray"]
         walked_scene_bytes = 128.0 * stats["inner_nodes"] + 48.0 * stats["triangles"]
         if tim["extend_launches"]:
             kname, k_ms_total, k_launches = "wf_extend_kernel", tim["extend_ms"], tim["extend_launches"]
-            # per ray: the pool record in (one 16-byte piece for a new camera ray, two for a continued path) and the hit out
-            algo_bytes_per_ray = 16.0 + 16.0 * (1.0 - my_paths / max(1.0, my_rays)) + 16.0
+            # per walk: the pool record in (one 16-byte piece for a new entry, two for a continued path) and the hit out;
+            # continued paths = rays - paths whether or not new entries share their walk
+            algo_bytes_per_ray = 16.0 + 16.0 * (my_rays - my_paths) / max(1.0, my_walks) + 16.0
             algo_scene_bytes = walked_scene_bytes
         else:
             kname, k_ms_total, k_launches = "path_kernel", tim["path_ms"], tim["path_launches"]
@@ -392,7 +394,8 @@ def main():
             algo_scene_bytes = float(stats["device_bytes"])
         k_ms = k_ms_total / max(1, k_launches)
         rays_per_launch = my_rays / max(1, k_launches)
-        algo_bytes_per_launch = rays_per_launch * algo_bytes_per_ray + algo_scene_bytes
+        walks_per_launch = (my_walks if tim["extend_launches"] else my_rays) / max(1, k_launches)
+        algo_bytes_per_launch = walks_per_launch * algo_bytes_per_ray + algo_scene_bytes
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pmc, pmc_source = counter_passes(workload_key(args, cfg))
         kp = (pmc or {}).get(kname, {})
@@ -408,9 +411,10 @@ def main():
             top = max(roofs, key=roofs.get)
             binding = {"roof": top, "frac": roofs[top], "all": roofs, "wave_cycle_split": kp.get("wave_cycle_split"),
                        "resident_waves_mean": kp.get("mean_waves_in_flight"), "resident_wave_limit": kp.get("resident_wave_limit")}
+        what = "closest-hit queries as upstream counts them; the first walk of a semantic batch is shared" if args.share_primary == 1 else "closest-hit queries"
         out = {
-            "metric": "Mrays/s (closest-hit queries), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
-                      else f"Mrays/s (closest-hit queries), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
+            "metric": f"Mrays/s ({what}), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
+                      else f"Mrays/s ({what}), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (procedural stand-in for the formula-1 OBJ, which upstream does not ship)",
@@ -432,8 +436,8 @@ def main():
                          "traffic_GBps": round(traffic_gbps, 1) if traffic_gbps else None,
                          "traffic_frac": round(traffic_gbps / HBM_PEAK_GBPS, 4) if traffic_gbps else None,
                          "kernel": kname, "kernel_ms_mean": round(k_ms, 4), "launches": int(k_launches),
-                         "algorithmic_bytes_per_ray": round(algo_bytes_per_ray, 2), "algorithmic_scene_bytes_per_launch": int(algo_scene_bytes),
-                         "algorithmic_bytes_per_launch": int(algo_bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1),
+                         "algorithmic_bytes_per_walk": round(algo_bytes_per_ray, 2), "algorithmic_scene_bytes_per_launch": int(algo_scene_bytes),
+                         "algorithmic_bytes_per_launch": int(algo_bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1), "walks_per_launch": round(walks_per_launch, 1),
                          "demand_bytes_per_ray": round(demand_bytes_per_ray, 1),
                          "demand_note": "32*box_tests + 36*triangle_tests per ray: requested of LDS/L1/L2/Infinity Cache, not of HBM",
                          "counter_passes": pmc_source},
