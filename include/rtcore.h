@@ -158,8 +158,8 @@ enum {
                                  primary ray (cuda/raytrace.cu:210, its README's "Hints"), share ONE closest-hit walk for it: a new pool entry
                                  stands for a pixel's run of samples of one batch, is walked once, and every sample is shaded from that hit with
                                  its own draws.  Same image bit for bit, RT_CNT_RAYS unchanged (rays as upstream counts them), RT_CNT_WALKS and
-                                 the box/triangle test counts drop.  0 = one walk per sample, as upstream executes it.  Off by itself when the
-                                 batch is longer than an eighth of a pool region */
+                                 the box/triangle test counts drop.  0 = one walk per sample, as upstream executes it.  Off by itself when a run
+                                 (the batch, or the call if that is shorter) is longer than an eighth of a pool region */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (Morton-code LBVH, rocPRIM sorts): a load-time option for large scenes, replacing

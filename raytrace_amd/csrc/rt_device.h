@@ -50,7 +50,8 @@ struct PathParams {
     // a pass covers the samples of [(run_base + k) * run_len, (run_base + k + 1) * run_len) that lie in the pass.
     // run_len = the semantic batch (one closest-hit query per pixel and batch), or 1 (one per sample, as upstream runs it).
     int run_len, run_base, n_runs;
-    uint32_t run_len_magic;
+    int run_lanes;                        // lanes the shading launch gives a new entry: min(run_len, n_samples)
+    uint32_t run_lanes_magic;
 };
 
 // samples [lo, hi) of run k of the pass (see PathParams)

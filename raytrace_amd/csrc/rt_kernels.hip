@@ -606,7 +606,7 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
 
 // Shading and queue compaction.  Workgroup b works on region (b mod regions) of pool `cur` -- workgroups that run at the
 // same time read different regions -- one lane per (entry, sample): a continuing path is one lane, a NEW entry (a pixel's
-// run of samples that share their primary ray and therefore its hit) as many lanes as the run is long, next to each
+// run of samples that share their primary ray and therefore its hit) as many lanes as a run of the pass can be long, next to each
 // other, each shading the same hit with its own sample's draws.  The lanes of a run read the same pool and shading
 // records (one cache line serves them), so the walk and its HBM traffic are spent once per run while the per-sample
 // arithmetic stays what it is.  The planner admitted only as many new entries as leave `lanes <= region_cap`.
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     const uint32_t local = within * RT_SHADE_BLOCK + threadIdx.x;          // lane's place among the region's lanes
     const uint32_t live = ctl->count[cur][reg * RT_QUEUE_STRIDE];
     const uint32_t continuing = ctl->gen_base[reg];                          // the new entries lie behind the continuing ones
-    const uint32_t lanes = continuing + (live - continuing) * (uint32_t)pp.run_len;
+    const uint32_t lanes = continuing + (live - continuing) * (uint32_t)pp.run_lanes;
     if (within * RT_SHADE_BLOCK >= lanes) return;                            // nothing of this region is left for this workgroup
     const int nxt = cur ^ 1;
     uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0, n_walks = 0;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     float4 o0, o1, o2;
     if (local < lanes) {
         uint32_t entry = local, nth = 0;                                     // pool entry of the region; sample of its run
-        if (local >= continuing) entry = continuing + udiv_by(local - continuing, (uint32_t)pp.run_len, pp.run_len_magic, nth);
+        if (local >= continuing) entry = continuing + udiv_by(local - continuing, (uint32_t)pp.run_lanes, pp.run_lanes_magic, nth);
         const uint32_t i = (reg << log2_region_cap) + entry;
         const float4 a = pool_load(&pools.p0[cur][i]), hq = pool_load(&pools.hit[i]);
         const uint32_t word = __float_as_uint(a.w);
@@ -1187,7 +1187,8 @@ static void set_runs(PathParams& pp, int run_len) {
     pp.per_tile_magic = magic_of(pp.per_tile);
     pp.tiles_x_magic = magic_of((uint32_t)pp.tiles_x);
     pp.batch_magic = magic_of((uint32_t)pp.batch);
-    pp.run_len_magic = magic_of((uint32_t)run_len);
+    pp.run_lanes = run_len < pp.n_samples ? run_len : pp.n_samples;      // no run of the pass has more samples than the pass
+    pp.run_lanes_magic = magic_of((uint32_t)pp.run_lanes);
 }
 
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
@@ -1268,9 +1269,10 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         R.pp.slots = pp.slots + (size_t)first * (size_t)pp.n_pixel * 3;
         // one closest-hit query per pixel and semantic batch, unless the option says one per sample or a run's survivors
         // would take more than an eighth of a region
-        const int run_len = (ctx->opt_share_primary && pp.batch > 1 && (uint32_t)pp.batch <= (cap / regions) / 8u) ? pp.batch : 1;
+        const uint32_t longest_run = (uint32_t)std::min(pp.batch, R.pp.n_samples);
+        const int run_len = (ctx->opt_share_primary && pp.batch > 1 && longest_run <= (cap / regions) / 8u) ? pp.batch : 1;
         set_runs(R.pp, run_len);
-        R.entry_yield = (uint32_t)run_len;      // the shading launch gives every new entry run_len lanes, whatever the slice cuts off
+        R.entry_yield = (uint32_t)R.pp.run_lanes;      // the shading launch gives every new entry that many lanes, whatever its run is cut to
         R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_runs;
         R.cur = 0;
         for (int& c : R.snap_cur) c = 0;
@@ -1454,7 +1456,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.sort_rays = ctx->opt_wf_sort;
     pp.hist = nullptr;
     pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
-    pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_len_magic = 0xFFFFFFFFu;
+    pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_lanes = 1; pp.run_lanes_magic = 0xFFFFFFFFu;
     const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
     if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
         pp.first_sample = first_sample;

@@ -525,7 +525,8 @@ def _runs(first, n, batch):
     ("material_box", dict(width=64, height=40, n_samples=16), 0, 16, 4, 11, 1, True),     # pool of 2048 entries: many refills
     ("material_box", dict(width=33, height=17, n_samples=10), 0, 10, 4, 11, 1, True),     # partial tiles, partial last batch
     ("material_box", dict(width=33, height=17, n_samples=16), 4, 7, 4, 12, 1, True),      # a later slice that ends inside a batch
-    ("material_box", dict(width=64, height=40, n_samples=16), 0, 16, 64, 11, 1, False),   # batch longer than an eighth of a region: not shared
+    ("material_box", dict(width=64, height=40, n_samples=64), 0, 64, 64, 11, 1, False),   # a run longer than an eighth of a region: not shared
+    ("material_box", dict(width=64, height=40, n_samples=8), 0, 8, 64, 18, 1, True),      # batch longer than the call: one run of 8 per pixel
     ("luyu", dict(width=96, height=60, n_samples=8, statue_tris=20000), 0, 8, 8, 14, 1, True),
     ("formula1", dict(width=96, height=60, n_samples=16, detail=0.05, tex_size=64), 0, 16, 16, 22, 1, True),   # pool larger than the job
     ("formula1", dict(width=96, height=60, n_samples=16, detail=0.05, tex_size=64), 0, 16, 4, 14, 2, True),    # two pipelines split the samples
