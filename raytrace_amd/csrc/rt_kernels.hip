@@ -637,24 +637,27 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
         uint32_t entry = local, nth = 0;                                     // pool entry of the region; sample of its run
         if (local >= continuing) entry = continuing + udiv_by(local - continuing, (uint32_t)pp.run_lanes, pp.run_lanes_magic, nth);
         const uint32_t i = (reg << log2_region_cap) + entry;
+        // a new entry: origin, throughput and depth are implied, and which run of samples it is follows from its place
+        // in the refill, as wf_generate_kernel counted it out; any other path: second and third record.  Which of the two
+        // an entry is follows from its place as well, so all of a path's records are asked for at once.
+        float4 b = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], 0.0f);
+        float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
         const float4 a = pool_load(&pools.p0[cur][i]), hq = pool_load(&pools.hit[i]);
+        if (entry < continuing) {
+            b = pool_load(&pools.p1[cur][i]);
+            c = pool_load(&pools.p2[cur][i]);
+        }
         const uint32_t word = __float_as_uint(a.w);
         if ((int)word >= 0) {                                        // -1: nothing was traced for this entry
             const int pixel = (int)(word & RT_PIXEL_MASK);
-            // a new entry: origin, throughput and depth are implied, and which run of samples it is follows from its place
-            // in the refill, as wf_generate_kernel counted it out; any other path: second and third record
-            float4 b = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], 0.0f);
-            float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
             int sample, s_hi;
-            if (word & RT_FRESH_PATH) {
+            if (entry >= continuing) {
                 uint32_t in_tile;
                 (void)udiv_by(ctl->gen_rem + ctl->gen_prefix[reg] + (entry - continuing), pp.per_tile, pp.per_tile_magic, in_tile);
                 int s_lo;
                 run_samples(pp, in_tile >> 8, s_lo, s_hi);
                 sample = s_lo + (int)nth;
             } else {
-                b = pool_load(&pools.p1[cur][i]);
-                c = pool_load(&pools.p2[cur][i]);
                 sample = __float_as_int(b.w);
                 s_hi = sample + 1;
             }
