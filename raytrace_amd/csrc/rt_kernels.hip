@@ -1264,6 +1264,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         int snap_cur[RT_CTL_RING];
         unsigned iter;
         bool drained;
+        bool all_at_once;               // every entry of the pass starts in the first iteration
     } run[2];
     for (int l = 0; l < n_lanes; l++) {
         rt_context::WfLane& L = ctx->lanes[l];
@@ -1280,6 +1281,10 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         set_runs(R.pp, run_len);
         R.entry_yield = (uint32_t)R.pp.run_lanes;      // the shading launch gives every new entry that many lanes, whatever its run is cut to
         R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_runs;
+        // A pass whose entries all fit the first refill needs no look at the pool's population: iteration i traces segment
+        // i of every path, so the shading of iteration max_depth ends the last of them.  (An interactive frame of a few
+        // samples otherwise pays up to eight empty iterations before the snapshots tell.)
+        R.all_at_once = R.total <= (unsigned long long)regions * ((cap / regions) / R.entry_yield);
         R.cur = 0;
         for (int& c : R.snap_cur) c = 0;
         R.iter = 0;
@@ -1304,6 +1309,11 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                 if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 timing_end(ctx, tk, ls);
+                if (R.all_at_once && R.iter >= (unsigned)pp.max_depth) {      // that shading ended the pass's last paths
+                    HIP_TRY(hipGetLastError());
+                    R.drained = true; live--;
+                    continue;
+                }
             }
             hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, R.pp.per_tile, R.entry_yield,
                                ctx->d_counters);
