@@ -215,6 +215,7 @@ struct WfCtl {
     uint32_t gen_tile;              // ... and divided by them: the tile the refill starts in
     // closest-hit launch under RT_OPT_COUNTERS: earliest wave start, latest wave end, sum of wave ends (100 MHz ticks), waves that did work
     unsigned long long t_first, t_last, t_end_sum, n_worked;
+    uint32_t iter, last_gen_iter;   // refills planned so far in this pass; the last one of them that started new entries
     // ---- device only ----
     uint32_t queue_next[RT_QUEUES * RT_QUEUE_STRIDE];   // closest-hit launch: per queue, first entry no wave has claimed yet (one cache line each)
     uint32_t gen_base[RT_REGIONS_MAX];                  // per region: first place the current refill writes (= survivors in front of it)
@@ -222,7 +223,7 @@ struct WfCtl {
     uint32_t live_prefix[RT_REGIONS_MAX + 1];           // live entries in the regions before r, after the refill
     uint32_t count[2][RT_REGIONS_MAX * RT_QUEUE_STRIDE];   // entries in region r of pool k (one cache line each)
 };
-#define RT_CTL_HEAD_BYTES 72
+#define RT_CTL_HEAD_BYTES 80
 static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads back exactly the head of the control block");
 
 // One workgroup of RT_REGIONS_MAX threads, thread r for region r: sizes the refill of pool `nxt` (free room per region
@@ -277,6 +278,9 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         ctl->count_total[nxt ^ 1] = 0;
         ctl->gen_count = n;
         ctl->regions = regions;
+        const uint32_t it = ctl->iter;
+        if (n) ctl->last_gen_iter = it;
+        ctl->iter = it + 1u;
         ctl->gen_first = ctl->cursor;
         ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
         ctl->gen_tile = (uint32_t)(ctl->cursor / per_tile);
@@ -1264,7 +1268,8 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         int snap_cur[RT_CTL_RING];
         unsigned iter;
         bool drained;
-        bool all_at_once;               // every entry of the pass starts in the first iteration
+        bool stop_known;                // the iteration whose shading ends the pass is known ...
+        unsigned stop_at;               // ... and is this one
     } run[2];
     for (int l = 0; l < n_lanes; l++) {
         rt_context::WfLane& L = ctx->lanes[l];
@@ -1284,7 +1289,9 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         // A pass whose entries all fit the first refill needs no look at the pool's population: iteration i traces segment
         // i of every path, so the shading of iteration max_depth ends the last of them.  (An interactive frame of a few
         // samples otherwise pays up to eight empty iterations before the snapshots tell.)
-        R.all_at_once = R.total <= (unsigned long long)regions * ((cap / regions) / R.entry_yield);
+        R.stop_known = R.total <= (unsigned long long)regions * ((cap / regions) / R.entry_yield);
+        R.stop_at = (unsigned)std::max(1, pp.max_depth);
+        // (Longer passes learn the iteration of the last start from the snapshots, a group late but well before it matters.)
         R.cur = 0;
         for (int& c : R.snap_cur) c = 0;
         R.iter = 0;
@@ -1309,7 +1316,9 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                 if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
                 timing_end(ctx, tk, ls);
-                if (R.all_at_once && R.iter >= (unsigned)pp.max_depth) {      // that shading ended the pass's last paths
+                // iteration i traces segment i - j of the paths started in iteration j, so the shading of iteration
+                // (last start) + max_depth ends the pass's last paths
+                if (R.stop_known && R.iter >= R.stop_at) {
                     HIP_TRY(hipGetLastError());
                     R.drained = true; live--;
                     continue;
@@ -1342,6 +1351,10 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                     const unsigned q = (g - 1) % RT_CTL_RING;
                     HIP_TRY(hipEventSynchronize(L.ctl_ev[q]));
                     if (L.h_ctl[q].cursor >= R.total && L.h_ctl[q].count_total[R.snap_cur[q]] == 0) { R.drained = true; live--; }
+                    else if (L.h_ctl[q].cursor >= R.total && !R.stop_known) {
+                        R.stop_known = true;
+                        R.stop_at = L.h_ctl[q].last_gen_iter + (unsigned)std::max(1, pp.max_depth);
+                    }
                 }
             }
             if (++R.iter > (1u << 26)) return fail(RT_ERR_DEVICE, "rt_raytrace: wavefront pass did not drain");
