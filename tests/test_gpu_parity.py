@@ -440,6 +440,31 @@ def test_full_size_sample_split_sums_to_the_whole_frame(gpu_ctx):
     assert cnt[capi.CNT_PATHS] == 2000 * 1200 * 32 and np.isfinite(whole).all() and whole.mean() > 0
 
 
+def test_full_size_shared_walk_equals_every_ray_walked(gpu_ctx):
+    """Size-independent property at the benchmark's full frame and default pool size: with the first walk of a semantic
+    batch shared (the library's default) the buffer and every per-sample count are those of one walk per sample; only
+    the walks run are fewer, by exactly the primaries saved."""
+    p = Pair(gpu_ctx, scene.formula1(width=2000, height=1200, n_samples=48, detail=0.3, tex_size=256))
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 27)
+    try:
+        every, c0 = p.gpu_render(0, 48, 16, counters=False)
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+        shared, c1 = p.gpu_render(0, 48, 16, counters=False)
+        # a slice that ends inside a batch, added to an earlier slice: 32 + 16 samples in two calls
+        part, _ = p.gpu_render(0, 32, 16, counters=False)
+        part, _ = p.gpu_render(32, 16, 16, accum=part, counters=False)
+    finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(every, shared) and same_f32(every, part)
+    npix = 2000 * 1200
+    assert c0[capi.CNT_RAYS] == c1[capi.CNT_RAYS] and c0[capi.CNT_PATHS] == c1[capi.CNT_PATHS] == npix * 48
+    assert c0[capi.CNT_WALKS] == c0[capi.CNT_RAYS]
+    assert c1[capi.CNT_WALKS] == c1[capi.CNT_RAYS] - npix * 48 + npix * 3
+
+
 def test_stress_scene_at_its_real_size(gpu_ctx):
     """The 30 M-triangle scene as benchmarked (8x8 instances of 470k triangles, 66 objects, 4.4 GB packed, deepest stacks,
     packed indices near 2^25) at the full 3840x2160 frame: every primary ray and 250k incoherent secondary rays are traced
