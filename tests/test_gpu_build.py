@@ -155,3 +155,47 @@ def test_device_build_of_the_30m_triangle_scene_is_fast_and_agrees_with_upstream
     finally:
         ref.close()
         own.close()
+
+
+def test_device_build_is_repeatable_and_the_code_bit_hierarchy_still_works(monkeypatch):
+    """The agglomeration numbers its inner nodes in the order the hardware makes them; nothing a ray sees may depend on
+    that: two builds of one scene render the same buffer bit for bit and count the same tests.  The older hierarchy (the
+    one the Morton code bits give, RT_BUILD_TREE=0) stays selectable and agrees with the exhaustive search as well."""
+    import torch
+    asm = scene.formula1(width=160, height=96, n_samples=8, detail=0.1, tex_size=64)
+    cfg = asm.config
+    objs = scene.finalize(asm)
+    npix = cfg.width * cfg.height
+
+    def render():
+        ctx = capi.Context(0)
+        try:
+            ctx.set_option(capi.OPT_GPU_BVH, 1)
+            ctx.set_option(capi.OPT_COUNTERS, 1)
+            ctx.upload_scene([(t, None) for t, _ in objs], asm.materials, asm.textures)
+            ctx.init_randstate(SEED, cfg.width, cfg.height)
+            ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+            d = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.raytrace(npix, 0, 8, 4, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+            c = ctx.counters()
+            rays = np.concatenate([orc.primary_rays(orc.make_params(cfg, SEED, 4), 0)[::5], random_rays(np.random.RandomState(11), 4000, -150.0, 150.0)])
+            return d.cpu().numpy(), c, _hits(ctx, rays), rays
+        finally:
+            ctx.close()
+
+    a, ca, ha, rays = render()
+    b, cb, hb, _ = render()
+    assert same_f32(a, b)
+    for k in (capi.CNT_RAYS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_SHADED):
+        assert ca[k] == cb[k], k
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(ha, hb))
+    monkeypatch.setenv("RT_BUILD_TREE", "0")
+    c, cc, hc, _ = render()
+    oracle = orc.Scene(objs, asm.materials, asm.textures)
+    brute = oracle.closest_hit_brute(rays)
+    for name, h in (("agglomerated", ha), ("code bits", hc)):
+        t = h[2]
+        assert (t >= brute).all(), name                        # never nearer than the nearest triangle
+        assert (bits(t) == bits(brute)).mean() > 0.995, name
+    assert cc[capi.CNT_TRI_TESTS] > ca[capi.CNT_TRI_TESTS]       # what the better leaves are for
