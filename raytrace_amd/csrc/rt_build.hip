@@ -249,6 +249,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void fit_kernel(const RawTri* __restri
 // search (16, 32 places) made slightly worse trees.
 // ---------------------------------------------------------------------------
 #define PLOC_RADIUS 8
+#define PLOC_OBJECT_RADIUS 1024
 constexpr uint32_t WHOLE_BIT = 0x80000000u;     // object word: the cluster holds every leaf of its object (or of several objects)
 
 struct Clusters {
@@ -257,13 +258,19 @@ struct Clusters {
     uint32_t* leaves;      // leaves below it
 };
 
-__global__ __launch_bounds__(BUILD_BLOCK) void nearest_kernel(uint32_t count, Clusters c, uint32_t radius, uint32_t* __restrict__ nearest) {
+// `objects_join`: 0 while parts of objects are left -- whole objects then wait, because their places in the array follow
+// the object numbers, which say nothing about where they are; once only whole objects are left they are few, the
+// search is as wide as the array (up to PLOC_OBJECT_RADIUS), and the tree above the objects is a true agglomeration.
+__global__ __launch_bounds__(BUILD_BLOCK) void nearest_kernel(uint32_t count, Clusters c, uint32_t radius, int objects_join, uint32_t* __restrict__ nearest,
+                                                              uint32_t* parts_left) {
     const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
     if (i >= count) return;
     const float4 lo = c.lo[i], hi = c.hi[i];
     const uint32_t mine = __float_as_uint(lo.w);
     uint32_t best = NONE;
     float best_area = INFINITY;
+    if (!(mine & WHOLE_BIT)) *parts_left = 1u;            // every writer writes the same value
+    else if (!objects_join) { nearest[i] = NONE; return; }
     const uint32_t from = i >= radius ? i - radius : 0u, to = min(count - 1u, i + radius);
     for (uint32_t j = from; j <= to; j++) {
         if (j == i) continue;
@@ -637,7 +644,8 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
         BUILD_TRY(hipGetLastError());
     } else {
         Clusters cl[2] = {};
-        uint32_t *d_nearest = nullptr, *d_goes_on = nullptr, *d_place = nullptr, *d_made = nullptr;
+        uint32_t *d_nearest = nullptr, *d_goes_on = nullptr, *d_place = nullptr, *d_made = nullptr, *d_parts_left = nullptr;
+        bool objects_join = false;
         for (Clusters& c : cl) {
             BUILD_TRY(tmp.get(&c.lo, m));
             BUILD_TRY(tmp.get(&c.hi, m));
@@ -651,6 +659,7 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
         BUILD_TRY(tmp.get(&d_goes_on, (size_t)m + 1));
         BUILD_TRY(tmp.get(&d_place, (size_t)m + 1));
         BUILD_TRY(tmp.get(&d_made, 1));
+        BUILD_TRY(tmp.get(&d_parts_left, 1));
         BUILD_TRY(hipMemsetAsync(d_made, 0, sizeof(uint32_t), nullptr));
         hipLaunchKernelGGL(triangle_clusters_kernel, dim3(blocks_for(n)), dim3(BUILD_BLOCK), 0, nullptr, d_tris, d_ids_sorted, n, d_first, n_objects, cl[0]);
         BUILD_TRY(hipGetLastError());
@@ -662,15 +671,22 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
         const uint32_t radius = radius_env ? (uint32_t)std::max(1, std::atoi(radius_env)) : PLOC_RADIUS;
         uint32_t count = m;
         for (int round = 0; count > 1; round++) {
-            hipLaunchKernelGGL(nearest_kernel, dim3(blocks_for(count)), dim3(BUILD_BLOCK), 0, nullptr, count, cl[0], radius, d_nearest);
+            BUILD_TRY(hipMemsetAsync(d_parts_left, 0, sizeof(uint32_t), nullptr));
+            hipLaunchKernelGGL(nearest_kernel, dim3(blocks_for(count)), dim3(BUILD_BLOCK), 0, nullptr, count, cl[0], objects_join ? (uint32_t)PLOC_OBJECT_RADIUS : radius,
+                               objects_join ? 1 : 0, d_nearest, d_parts_left);
             hipLaunchKernelGGL(merge_triangles_kernel, dim3(blocks_for(count)), dim3(BUILD_BLOCK), 0, nullptr, count, cl[0], cl[1], d_nearest, b, d_made, d_first, d_goes_on);
             BUILD_TRY(hipGetLastError());
             BUILD_TRY(hipMemsetAsync(d_goes_on + count, 0, sizeof(uint32_t), nullptr));
             BUILD_TRY(rocprim::exclusive_scan(d_scan_temp, scan_bytes, d_goes_on, d_place, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), nullptr));
             hipLaunchKernelGGL(compact_kernel, dim3(blocks_for(count)), dim3(BUILD_BLOCK), 0, nullptr, count, cl[1], cl[0], d_goes_on, d_place);
             BUILD_TRY(hipGetLastError());
-            uint32_t left = 0;
+            uint32_t left = 0, parts_left = 0;
             BUILD_TRY(hipMemcpy(&left, d_place + count, sizeof left, hipMemcpyDeviceToHost));
+            BUILD_TRY(hipMemcpy(&parts_left, d_parts_left, sizeof parts_left, hipMemcpyDeviceToHost));
+            if (!objects_join && !parts_left) {          // this round saw whole objects only (and joined nothing): from now on they join
+                objects_join = true;
+                continue;
+            }
             // the pair with the smallest box of a round chose each other, so every round joins at least one pair
             if (left == 0 || left >= count || round > 4096) { err = "agglomeration stalled at " + std::to_string(count) + " clusters"; release_device_scene(out); return -1; }
             count = left;
