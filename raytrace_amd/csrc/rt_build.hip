@@ -244,9 +244,9 @@ __global__ __launch_bounds__(BUILD_BLOCK) void fit_kernel(const RawTri* __restri
 // asked, the boxes decide who is joined, which is what the code-bit hierarchy lacks.  An object's clusters join among
 // themselves until the object is one cluster -- its subtree then has the object's own tight box, and a ground plane next
 // to a car part in the order does not swallow it -- and whole objects join each other the same way.
-// Measured against the code-bit hierarchy over blind pairs: formula1 6422 -> 8384 Mrays/s, 30 M triangles 2155 -> 3567
+// Measured against the code-bit hierarchy over blind pairs: formula1 6422 -> 9083 Mrays/s, 30 M triangles 2155 -> 3621
 // (upstream's median-split trees: 8162 and 3236), and the build is quicker (30 M triangles: 170 -> 92 ms).  A wider
-// search (16, 32 places) made slightly worse trees.
+// search (12 to 32 places) changes little.
 // ---------------------------------------------------------------------------
 #define PLOC_RADIUS 8
 #define PLOC_OBJECT_RADIUS 1024
