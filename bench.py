@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the bounded CPU-baseline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-device-tree", action="store_true", help="skip the extra timing on the device-built tree")
     ap.add_argument("--save-image", default="")
     ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = library default)")
     ap.add_argument("--pass-spp", type=int, default=0, help="samples per buffered pass (0 = library default)")
@@ -422,7 +423,7 @@ def main():
                                    f"{frame_spp}-spp frame traced in steps of {spp} spp per GPU, semantic batch {args.batch}",
                        "triangles": int(stats["triangles"]), "objects": int(stats["objects"]), "spp_per_step_per_gpu": spp,
                        "mode": args.mode or "library default (wavefront)",
-                       "tree": "built on the device (LBVH, RT_OPT_GPU_BVH)" if args.gpu_bvh else "upstream's median-split trees, re-packed",
+                       "tree": "built on the device by agglomeration (RT_OPT_GPU_BVH)" if args.gpu_bvh else "upstream's median-split trees, re-packed",
                        "partition": f"spp-split x{world}, scene replicated, RCCL reduce per step" if world > 1 else "single GPU",
                        "reduce": reduce_via,
                        "first_walk": "shared by the samples of a semantic batch (RT_OPT_SHARE_PRIMARY = 1)" if args.share_primary == 1
@@ -453,6 +454,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.gpu_bvh:
             out["cpu_baseline"] = cpu_baseline(asm, objs, args)
             out["cpu_baseline"]["cfg1"] = cpu_cfg1(args)
+        if world == 1 and wavefront_mode and args.share_primary < 0 and not args.gpu_bvh and not args.no_device_tree:
+            try:
+                out["device_tree"] = device_tree_line(args, asm, cfg, objs, device_index, spp, frame_spp)
+            except Exception as e:               # an extra; the line stands without it
+                out["device_tree"] = {"error": str(e)}
         if args.save_image:
             # with several ranks the picture is the reduced buffer of the last step, which holds every rank's samples so far
             save_image(ctx, reduced if world > 1 else accum, cfg, (args.warmup + args.steps) * spp * world, args.save_image)
@@ -463,6 +469,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def device_tree_line(args, asm, cfg, objs, device_index, spp, frame_spp):
+    """The same steps on the library's fastest configuration: the scene tree built on the device (RT_OPT_GPU_BVH: another
+    tree than upstream's, so exact ties may go to another triangle -- why it is not the headline) and the first walk of a
+    batch shared.  A context of its own; timed like the headline (synchronize on both sides)."""
+    import torch
+    from raytrace_amd import capi
+    ctx = capi.Context(device_index)
+    try:
+        ctx.set_option(capi.OPT_GPU_BVH, 1)
+        t0 = time.time()
+        ctx.upload_scene([(t, None) for t, _ in objs], asm.materials, asm.textures)
+        t_load = time.time() - t0
+        st = ctx.scene_stats()
+        ctx.init_randstate(SEED, cfg.width, cfg.height)
+        ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+        npix = cfg.width * cfg.height
+        accum = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.raytrace(npix, 0, spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette, accum.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ctx.reset_counters()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ctx.raytrace(npix, (1 + k) * spp, spp, args.batch, cfg.max_depth, cfg.background, cfg.russian_roulette, accum.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cnt = ctx.counters()
+        ms = dt * 1e3 / max(1, args.steps)
+        return {"option": "RT_OPT_GPU_BVH = 1 and RT_OPT_SHARE_PRIMARY = 1: tree built on the device by agglomeration, first walk of a batch shared",
+                "ms_per_step": round(ms, 3), "seconds_per_frame": round(ms * 1e-3 * frame_spp / spp, 3),
+                "upstream_rays_mrays_per_s": round(cnt[capi.CNT_RAYS] / dt / 1e6, 2),
+                "walks_executed_mrays_per_s": round(cnt[capi.CNT_WALKS] / dt / 1e6, 2),
+                "device_build_ms": round(st["gpu_build_ms"], 1), "triangle_copy_ms": round(st["gpu_copy_ms"], 1), "upload_call_s": round(t_load, 3)}
+    finally:
+        ctx.close()
 
 
 def cpu_cfg1(args):
