@@ -30,6 +30,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -556,7 +557,10 @@ void release_device_scene(DeviceScene& s) {
     for (void** p : ptrs) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 }
 
-int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& out, std::string& err) {
+// -2: the agglomeration made too little progress (it joins at least one pair a round, but a scene whose neighbours'
+// distances shrink steadily along the order joins ONLY one): the caller builds the code-bit hierarchy instead
+#define PLOC_MAX_ROUNDS 256
+static int build_impl(const rt_object* objects, int n_objects, DeviceScene& out, std::string& err, bool may_agglomerate) {
     out = DeviceScene();
     uint64_t total = 0;
     std::vector<uint32_t> first(n_objects + 1, 0);
@@ -572,7 +576,7 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
     // or two triangles, and as the experiment switch RT_BUILD_TREE=0 -- the one the code bits give over pairs of sorted
     // neighbours (Karras 2012)
     const char* tree_env = std::getenv("RT_BUILD_TREE");
-    const bool agglomerate = n >= 3 && !(tree_env && std::atoi(tree_env) == 0);
+    const bool agglomerate = may_agglomerate && n >= 3 && !(tree_env && std::atoi(tree_env) == 0);
     const uint32_t m = agglomerate ? n : (n + 1) / 2;          // leaves (agglomeration: room for as many, numbered sparsely)
     uint32_t inner = m - 1;                                     // inner nodes (agglomeration: as many as turn out)
     Scratch tmp;
@@ -688,7 +692,8 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
                 continue;
             }
             // the pair with the smallest box of a round chose each other, so every round joins at least one pair
-            if (left == 0 || left >= count || round > 4096) { err = "agglomeration stalled at " + std::to_string(count) + " clusters"; release_device_scene(out); return -1; }
+            if (left == 0 || left >= count) { err = "agglomeration stalled at " + std::to_string(count) + " clusters"; release_device_scene(out); return -1; }
+            if (round >= PLOC_MAX_ROUNDS) { release_device_scene(out); return -2; }
             count = left;
         }
         {
@@ -796,6 +801,13 @@ int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& 
     out.copy_ms = ms_copy;
     out.build_ms = ms_build;
     return 0;
+}
+
+int build_scene_on_device(const rt_object* objects, int n_objects, DeviceScene& out, std::string& err) {
+    const int rc = build_impl(objects, n_objects, out, err, true);
+    if (rc != -2) return rc;
+    std::fprintf(stderr, "rtcore: device build: the agglomeration needed more than %d rounds; building the hierarchy of the code bits instead\n", PLOC_MAX_ROUNDS);
+    return build_impl(objects, n_objects, out, err, false);
 }
 
 }  // namespace rtc

@@ -199,3 +199,36 @@ def test_device_build_is_repeatable_and_the_code_bit_hierarchy_still_works(monke
         assert (t >= brute).all(), name                        # never nearer than the nearest triangle
         assert (bits(t) == bits(brute)).mean() > 0.995, name
     assert cc[capi.CNT_TRI_TESTS] > ca[capi.CNT_TRI_TESTS]       # what the better leaves are for
+
+
+def test_device_build_falls_back_when_the_agglomeration_crawls(capfd):
+    """Triangles along a line whose gaps shrink steadily: every cluster prefers its right-hand neighbour, only the last two
+    choose each other, and the agglomeration joins one pair a round.  The builder gives up after a fixed number of
+    rounds and builds the hierarchy the code bits give; the hits are still those of the exhaustive search."""
+    n = 1500
+    gaps = 0.995 ** np.arange(n)
+    x = np.concatenate([[0.0], np.cumsum(gaps)[:-1]])
+    tris = np.zeros(n, dtype=capi.TRIANGLE_DTYPE)
+    for k in range(n):
+        tris["v"]["position"][k] = [[x[k], 0, 0], [x[k], 1, 0], [x[k], 0, 1]]
+        tris["v"]["normal"][k] = [[1, 0, 0]] * 3
+    mats = np.zeros(1, dtype=capi.MATERIAL_DTYPE)
+    mats["type"] = capi.MAT_LAMBERTIAN
+    mats["texture"] = -1
+    ctx = capi.Context(0)
+    try:
+        ctx.set_option(capi.OPT_GPU_BVH, 1)
+        ctx.upload_scene([(tris, None)], mats, [])
+        assert ctx.scene_stats()["triangles"] == n
+        assert "building the hierarchy of the code bits instead" in capfd.readouterr().err
+        rng = np.random.RandomState(5)
+        o = np.stack([rng.uniform(-5, x[-1] + 5, 3000), rng.uniform(0.05, 0.4, 3000), rng.uniform(0.05, 0.4, 3000)], axis=1)
+        d = np.stack([rng.choice([-1.0, 1.0], 3000), rng.uniform(-0.01, 0.01, 3000), rng.uniform(-0.01, 0.01, 3000)], axis=1)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([o, d], axis=1).astype(np.float32)
+        _, tr, t, _, _ = _hits(ctx, rays)
+        bvh = orc.build_bvh(tris)
+        brute = orc.Scene([(tris, bvh)], mats, []).closest_hit_brute(rays)
+        assert (bits(t) == bits(brute)).mean() > 0.995 and (t >= brute).all() and np.isfinite(t).mean() > 0.5
+    finally:
+        ctx.close()
