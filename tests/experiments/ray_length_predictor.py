@@ -1,5 +1,5 @@
-"""How well does a path segment's traversal length predict the next segment's?  (Analysis behind
-profiles/experiments/r02_tail.md; not a test.  Uses the CPU oracle, one ray per call, for its per-ray box-test count.)
+"""How well does a path segment's traversal length predict the next segment's?  (Analysis behind the note on the
+closest-hit launch's tail under profiles/experiments/; not a test.  Uses the CPU oracle, one ray per call, for its per-ray box-test count.)
 
     python tests/experiments/ray_length_predictor.py [n_paths=15000]
 """
