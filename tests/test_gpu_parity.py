@@ -512,12 +512,17 @@ def test_stress_scene_at_its_real_size(gpu_ctx):
     gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 27)
     try:
         got, gcnt = p.gpu_render(0, 4, 4)
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)                         # the library's default: one walk per pixel and batch
+        shared, scnt = p.gpu_render(0, 4, 4)
     finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
         gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
     assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
     assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2] and gcnt[capi.CNT_SHADED] == rcnt[3]
     assert gcnt[capi.CNT_MAX_STACK] > 11                                      # the private spill levels were in use
+    assert same_f32(shared, ref) and scnt[capi.CNT_RAYS] == rcnt[0] and scnt[capi.CNT_SHADED] == rcnt[3]
+    assert scnt[capi.CNT_WALKS] == rcnt[0] - 3 * cfg.width * cfg.height       # four samples, one batch: three camera walks saved per pixel
 
 
 def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
