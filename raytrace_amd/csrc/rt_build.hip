@@ -377,13 +377,13 @@ __global__ __launch_bounds__(BUILD_BLOCK) void packed_order_kernel(uint32_t n, B
     if (b.leaf_size[k] == 2u) packed_ids[at + 1] = sorted_ids[b.leaf_other[k]];
 }
 
-__global__ __launch_bounds__(BUILD_BLOCK) void depth_kernel(uint32_t inner, Binary b, uint32_t* __restrict__ even_flag, uint32_t* max_depth) {
+// depth of the binary hierarchy (a statistic; the records are cut by mark_records_kernel)
+__global__ __launch_bounds__(BUILD_BLOCK) void depth_kernel(uint32_t inner, Binary b, uint32_t* max_depth) {
     const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
     if (i >= inner) return;
     uint32_t d = 0;
     for (uint32_t p = b.parent[i]; p != NONE; p = b.parent[p]) d++;
     b.depth[i] = d;
-    even_flag[i] = (d & 1u) ? 0u : 1u;
     atomicMax(max_depth, d);
 }
 
@@ -393,13 +393,55 @@ __device__ __forceinline__ float half_area(const float* bx) {
     return (a == a && a > 0.0f) ? a : 0.0f;
 }
 
-// even-depth inner nodes, compacted: their sort key (level, then falling box area) and their number
+// The up to four slots of the record rooted at binary node `node`: its two children, and then, twice, the inner slot
+// with the largest box replaced by its own two children in place.  A ray is likelier to enter a larger box, so the
+// boxes most worth deciding in this visit are the ones below it; on a balanced tree this is the children's children,
+// on the lopsided trees an agglomeration makes it follows the large side down.
+__device__ __forceinline__ uint32_t record_slots(const Binary& b, uint32_t node, uint32_t slots[4]) {
+    uint32_t used = 2;
+    slots[0] = b.child[2 * (size_t)node];
+    slots[1] = b.child[2 * (size_t)node + 1];
+    for (int turn = 0; turn < 2; turn++) {
+        int widest = -1;
+        float area = -1.0f;
+        for (uint32_t k = 0; k < used; k++) {
+            if (slots[k] & LEAF_BIT) continue;
+            const float a = half_area(b.box + 6 * (size_t)slots[k]);
+            if (a > area) { area = a; widest = (int)k; }
+        }
+        if (widest < 0) break;
+        const uint32_t c = slots[widest];
+        for (uint32_t k = used; k > (uint32_t)widest + 1; k--) slots[k] = slots[k - 1];
+        slots[widest] = b.child[2 * (size_t)c];
+        slots[widest + 1] = b.child[2 * (size_t)c + 1];
+        used++;
+    }
+    return used;
+}
+
+// One level of records: every root of the frontier is marked and numbered with its level, the inner slots of its record
+// are the next frontier.
+__global__ __launch_bounds__(BUILD_BLOCK) void mark_records_kernel(const uint32_t* __restrict__ frontier, uint32_t count, Binary b, uint32_t level,
+                                                                   uint32_t* __restrict__ is_root, uint32_t* __restrict__ level_of,
+                                                                   uint32_t* __restrict__ next, uint32_t* next_count) {
+    const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t node = frontier[i];
+    is_root[node] = 1u;
+    level_of[node] = level;
+    uint32_t slots[4];
+    const uint32_t used = record_slots(b, node, slots);
+    for (uint32_t k = 0; k < used; k++)
+        if (!(slots[k] & LEAF_BIT)) next[atomicAdd(next_count, 1u)] = slots[k];
+}
+
+// the roots of the records, compacted: their sort key (level, then falling box area) and their number
 __global__ __launch_bounds__(BUILD_BLOCK) void even_keys_kernel(uint32_t inner, Binary b, const uint32_t* __restrict__ even_flag, const uint32_t* __restrict__ even_pos,
-                                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ nodes) {
+                                                                const uint32_t* __restrict__ level_of, uint64_t* __restrict__ keys, uint32_t* __restrict__ nodes) {
     const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
     if (i >= inner || !even_flag[i]) return;
     const uint32_t at = even_pos[i];
-    keys[at] = ((uint64_t)(b.depth[i] >> 1) << 32) | (uint64_t)(0xFFFFFFFFu - __float_as_uint(half_area(b.box + 6 * (size_t)i)));
+    keys[at] = ((uint64_t)min(level_of[i], 0xFFFFu) << 32) | (uint64_t)(0xFFFFFFFFu - __float_as_uint(half_area(b.box + 6 * (size_t)i)));
     nodes[at] = i;
 }
 
@@ -422,9 +464,9 @@ __device__ __forceinline__ uint32_t leaf_ref(const Binary& b, uint32_t leaf, uin
     return REF_LEAF | first | (first + 1 < n ? REF_PAIR : 0u);
 }
 
-// One thread per two-level record (in its final place): the node's children, or their children where a child is an inner node.
+// One thread per record (in its final place): the slots record_slots chooses below its root.
 __global__ __launch_bounds__(BUILD_BLOCK) void emit_records_kernel(uint32_t n4, uint32_t n, const uint32_t* __restrict__ sorted_nodes,
-                                                                   const uint32_t* __restrict__ rank_of, Binary b, Records rec, int upper_first) {
+                                                                   const uint32_t* __restrict__ rank_of, Binary b, Records rec) {
     const uint32_t r = blockIdx.x * BUILD_BLOCK + threadIdx.x;
     if (r >= n4) return;
     const uint32_t node = sorted_nodes[r];
@@ -443,13 +485,9 @@ __global__ __launch_bounds__(BUILD_BLOCK) void emit_records_kernel(uint32_t n4, 
         }
         used++;
     };
-    // a node's right child holds the higher Morton codes; slot 0 is visited first
-    for (int turn = 0; turn < 2; turn++) {
-        const int side = upper_first ? 1 - turn : turn;
-        const uint32_t c = b.child[2 * (size_t)node + side];
-        if (c & LEAF_BIT) put(c);
-        else { put(b.child[2 * (size_t)c + (upper_first ? 1 : 0)]); put(b.child[2 * (size_t)c + (upper_first ? 0 : 1)]); }
-    }
+    uint32_t slots[4];
+    const uint32_t chosen = record_slots(b, node, slots);
+    for (uint32_t k = 0; k < chosen; k++) put(slots[k]);
     for (uint32_t k = used; k < 4; k++) {
         for (int a = 0; a < 3; a++) { out.box[k][a] = INFINITY; out.box[k][3 + a] = -INFINITY; }
         out.ref[k] = REF_NONE;
@@ -728,14 +766,31 @@ static int build_impl(const rt_object* objects, int n_objects, DeviceScene& out,
         root_ref = REF_LEAF | 0u | (n > 1 ? REF_PAIR : 0u);
     } else {
         // ---- 5: even-depth inner nodes -> records, numbered by (level, falling area) ----
-        uint32_t *d_even = nullptr, *d_even_pos = nullptr, *d_max_depth = nullptr;
+        uint32_t *d_even = nullptr, *d_even_pos = nullptr, *d_max_depth = nullptr, *d_level = nullptr, *d_front[2] = {nullptr, nullptr}, *d_front_count = nullptr;
         BUILD_TRY(tmp.get(&d_even, (size_t)inner + 1));
         BUILD_TRY(tmp.get(&d_even_pos, (size_t)inner + 1));
         BUILD_TRY(tmp.get(&d_max_depth, 1));
+        BUILD_TRY(tmp.get(&d_level, inner));
+        BUILD_TRY(tmp.get(&d_front[0], inner));
+        BUILD_TRY(tmp.get(&d_front[1], inner));
+        BUILD_TRY(tmp.get(&d_front_count, 1));
         BUILD_TRY(hipMemsetAsync(d_max_depth, 0, sizeof(uint32_t), nullptr));
-        BUILD_TRY(hipMemsetAsync(d_even + inner, 0, sizeof(uint32_t), nullptr));
-        hipLaunchKernelGGL(depth_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_even, d_max_depth);
+        BUILD_TRY(hipMemsetAsync(d_even, 0, ((size_t)inner + 1) * sizeof(uint32_t), nullptr));
+        hipLaunchKernelGGL(depth_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_max_depth);
         BUILD_TRY(hipGetLastError());
+        // the records' roots, level after level from the top (a level's roots are the inner slots of the level above)
+        {
+            BUILD_TRY(hipMemcpy(d_front[0], &root_node, sizeof(uint32_t), hipMemcpyHostToDevice));
+            uint32_t count = 1;
+            for (uint32_t level = 0; count > 0; level++) {
+                if (level > inner) { err = "the hierarchy has a cycle"; release_device_scene(out); return -1; }
+                BUILD_TRY(hipMemsetAsync(d_front_count, 0, sizeof(uint32_t), nullptr));
+                hipLaunchKernelGGL(mark_records_kernel, dim3(blocks_for(count)), dim3(BUILD_BLOCK), 0, nullptr, (const uint32_t*)d_front[level & 1], count, b, level, d_even,
+                                   d_level, d_front[(level & 1) ^ 1], d_front_count);
+                BUILD_TRY(hipGetLastError());
+                BUILD_TRY(hipMemcpy(&count, d_front_count, sizeof count, hipMemcpyDeviceToHost));
+            }
+        }
         {
             size_t bytes = 0;
             BUILD_TRY(rocprim::exclusive_scan(nullptr, bytes, d_even, d_even_pos, 0u, (size_t)inner + 1, rocprim::plus<uint32_t>(), nullptr));
@@ -752,14 +807,14 @@ static int build_impl(const rt_object* objects, int n_objects, DeviceScene& out,
         BUILD_TRY(tmp.get(&d_n4, n4));
         BUILD_TRY(tmp.get(&d_n4_sorted, n4));
         BUILD_TRY(tmp.get(&d_rank, inner));
-        hipLaunchKernelGGL(even_keys_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_even, d_even_pos, d_k4, d_n4);
+        hipLaunchKernelGGL(even_keys_kernel, dim3(blocks_for(inner)), dim3(BUILD_BLOCK), 0, nullptr, inner, b, d_even, d_even_pos, (const uint32_t*)d_level, d_k4, d_n4);
         BUILD_TRY(hipGetLastError());
         {
             size_t bytes = 0;
-            BUILD_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 40, nullptr));
+            BUILD_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 48, nullptr));
             char* d_temp = nullptr;
             BUILD_TRY(tmp.get(&d_temp, bytes));
-            BUILD_TRY(rocprim::radix_sort_pairs(d_temp, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 40, nullptr));
+            BUILD_TRY(rocprim::radix_sort_pairs(d_temp, bytes, d_k4, d_k4_sorted, d_n4, d_n4_sorted, (size_t)n4, 0, 48, nullptr));
         }
         hipLaunchKernelGGL(rank_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, d_n4_sorted, d_rank);
         // ---- 6: records, slot order, stack need ----
@@ -771,10 +826,8 @@ static int build_impl(const rt_object* objects, int n_objects, DeviceScene& out,
         BUILD_TRY(tmp.get(&rec.arrived4, n4));
         BUILD_TRY(tmp.get(&rec.need4, n4));
         BUILD_TRY(hipMemsetAsync(rec.arrived4, 0, (size_t)n4 * sizeof(uint32_t), nullptr));
-        const char* order_env = std::getenv("RT_BUILD_ORDER");
-        const int order = order_env ? std::atoi(order_env) : 0;        // experiment switch: 0 = deepest last, 1 = lower codes first, 2 = higher codes first
-        hipLaunchKernelGGL(emit_records_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, n, d_n4_sorted, d_rank, b, rec, order == 2 ? 1 : 0);
-        hipLaunchKernelGGL(need_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, rec, order == 0 ? 1 : 0);
+        hipLaunchKernelGGL(emit_records_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, n, d_n4_sorted, d_rank, b, rec);
+        hipLaunchKernelGGL(need_kernel, dim3(blocks_for(n4)), dim3(BUILD_BLOCK), 0, nullptr, n4, rec, 1);
         BUILD_TRY(hipGetLastError());
         BUILD_TRY(hipMemcpy(&stack_need, rec.need4, sizeof stack_need, hipMemcpyDeviceToHost));      // record 0 is the root
         BUILD_TRY(hipMemcpy(root_box, b.box + 6 * (size_t)root_node, sizeof root_box, hipMemcpyDeviceToHost));
