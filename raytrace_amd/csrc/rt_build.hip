@@ -18,7 +18,8 @@
 //   4. a node's box is the union of its children's, written when it is made;
 //      (3' and 4', RT_BUILD_TREE=0 and scenes of one or two triangles: leaves = pairs of neighbours in sorted order, the
 //      hierarchy the code bits give after Karras 2012, boxes bottom-up -- 13 to 40 % slower to walk)
-//   5. the inner nodes at even depth become two-level records: numbered breadth first, larger boxes first inside a level
+//   5. the hierarchy is cut into four-slot records from the top (a record's slots: its root's children, then twice the
+//      inner slot with the largest box opened); the records are numbered level by level, larger boxes first inside a level
 //      (second radix sort), so that the records every walk starts with lead the array (the kernels keep a prefix in LDS);
 //   6. stack need bottom-up over the two-level records; the slots of a record are ordered so that the slot with the
 //      deepest subtree is visited last -- nothing waits on the stack while the walk is below it -- which keeps the
