@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
     ap.add_argument("--wf-lanes", type=int, default=0)
+    ap.add_argument("--share-equal", type=int, default=-1, help="1/0: samples that leave a mirror or glass along one ray share its walk / every continued path is walked (default: 0 for the headline, library default beside it)")
     ap.add_argument("--share-primary", type=int, default=-1, help="1/0: one closest-hit walk per pixel and semantic batch / one per sample (default: library default)")
     ap.add_argument("--hot-tune", type=int, default=-1, help="1/0: number the LDS-resident node records by measured visits (default: library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the scene tree on the device (RT_OPT_GPU_BVH) instead of re-packing upstream's trees")
@@ -207,6 +208,9 @@ def main():
         ctx.set_option(capi.OPT_HOT_TUNE, args.hot_tune)
     # the headline counts closest-hit queries as upstream executes them, so it walks every one (see `shared_primary` on the line)
     ctx.set_option(capi.OPT_SHARE_PRIMARY, args.share_primary if args.share_primary >= 0 else 0)
+    # likewise the walks of continued paths whose rays coincide (RT_OPT_SHARE_EQUAL): shared only where the first walk is
+    share_equal = args.share_equal if args.share_equal >= 0 else (1 if args.share_primary == 1 else 0)
+    ctx.set_option(capi.OPT_SHARE_EQUAL, share_equal)
     wavefront_mode = args.mode in (None, "", "wavefront")
     ctx.init_randstate(SEED, cfg.width, cfg.height)
     ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
@@ -350,9 +354,11 @@ def main():
     shared_line = None
     if wavefront_mode and args.share_primary < 0:
         ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+        ctx.set_option(capi.OPT_SHARE_EQUAL, 1 if args.share_equal < 0 else args.share_equal)
         run_step(0)
         sh = timed_region(1, args.steps)
         ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        ctx.set_option(capi.OPT_SHARE_EQUAL, share_equal)
         accum.zero_()
         sh_ms = sh["elapsed"] * 1e3 / max(1, args.steps)
         shared_line = {"option": "RT_OPT_SHARE_PRIMARY = 1 (library default): one closest-hit walk per pixel and semantic batch, same image bit for bit",

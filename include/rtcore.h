@@ -160,6 +160,10 @@ enum {
                                  its own draws.  Same image bit for bit, RT_CNT_RAYS unchanged (rays as upstream counts them), RT_CNT_WALKS and
                                  the box/triangle test counts drop.  0 = one walk per sample, as upstream executes it.  Off by itself when a run
                                  (the batch, or the call if that is shorter) is longer than an eighth of a pool region */
+    RT_OPT_SHARE_EQUAL = 20,  /* wavefront: 1 (default) = samples of one pixel that arrive at a hit along one ray and leave a mirror, a pane of
+                                 glass (the same way of its two) or a fuzz-free metal reflection leave along one ray again, bit for bit: it
+                                 is walked once and every such sample is shaded from that hit.  Same image, RT_CNT_RAYS unchanged,
+                                 RT_CNT_WALKS drops.  0 = every continued path is walked */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (agglomeration in Morton order, rocPRIM sort and scans; 30 M triangles in under 0.1 s),

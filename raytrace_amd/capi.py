@@ -44,6 +44,7 @@ OPT_WF_LANES = 16
 OPT_GPU_BVH = 17
 OPT_HOT_TUNE = 18
 OPT_SHARE_PRIMARY = 19
+OPT_SHARE_EQUAL = 20
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 GROUP_ID_BYTES = 128

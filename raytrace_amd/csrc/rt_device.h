@@ -501,9 +501,13 @@ __device__ __forceinline__ void prepare_hit(const SceneDev& sc, const RayD& ray,
 
 // The rest of the iteration for ONE sample: miss / light / roulette / scatter with that sample's draws.  `ray` is written
 // only when the path goes on.  Counts are per sample (what upstream executes per sample), whoever shared the preparation.
+// `repeatable` (set when the path goes on): the new ray does not depend on the sample's random vector -- a mirror, glass
+// (one of two rays, by the sample's decision draw), a metal without fuzz on its reflecting branch -- so other samples
+// that arrived along the same ray may leave along the same ray.
 template <bool COUNT>
 __device__ __forceinline__ bool scatter_hit(const HitPrep& q, const ShadeConst& k, RayD& ray, uint32_t pixel, uint32_t sample, uint32_t bounce,
-                                            v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
+                                            v3& color, uint32_t& n_shaded, uint32_t& n_tex, bool& repeatable) {
+    repeatable = false;
     if (!q.hit) {
         color = vmul(color, k.ambient); return true;      // raytrace.cu:220-223
     } else {
@@ -540,10 +544,12 @@ __device__ __forceinline__ bool scatter_hit(const HitPrep& q, const ShadeConst& 
                     color = vmul(color, vscale(hit_color, cos_theta));
                 } else {
                     dir = vadd(vnormalize(reflect3(rd, nn)), vscale(rnd, metal_fuzz));
+                    repeatable = metal_fuzz == 0.0f;
                 }
             } else if (mtype == RT_MAT_REFLECTIVE) {
                 dir = reflect3(rd, normal);
                 color = vmul(color, hit_color);
+                repeatable = true;
             } else if (mtype == RT_MAT_REFRACTIVE) {
                 v3 outward;
                 float ni_over_nt, cosine;
@@ -573,6 +579,7 @@ __device__ __forceinline__ bool scatter_hit(const HitPrep& q, const ShadeConst& 
                 // uninitialised when the draw is exactly 1.0 (raytrace.cu:182-187), here that case reflects too.
                 if (decision < reflect_prob || !refracted) dir = reflect3(rd, normal);
                 color = vmul(color, hit_color);
+                repeatable = true;
             } else {
                 scattered = false;
             }
@@ -593,7 +600,16 @@ __device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& 
                                           uint32_t sample, uint32_t bounce, v3& color, uint32_t& n_shaded, uint32_t& n_tex) {
     HitPrep q;
     prepare_hit(sc, ray, h, q);
-    return scatter_hit<COUNT>(q, k, ray, pixel, sample, bounce, color, n_shaded, n_tex);
+    bool repeatable;
+    return scatter_hit<COUNT>(q, k, ray, pixel, sample, bounce, color, n_shaded, n_tex, repeatable);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const SceneDev& sc, const ShadeConst& k, RayD& ray, const Hit& h, uint32_t pixel,
+                                          uint32_t sample, uint32_t bounce, v3& color, uint32_t& n_shaded, uint32_t& n_tex, bool& repeatable) {
+    HitPrep q;
+    prepare_hit(sc, ray, h, q);
+    return scatter_hit<COUNT>(q, k, ray, pixel, sample, bounce, color, n_shaded, n_tex, repeatable);
 }
 
 #endif

@@ -187,9 +187,14 @@ __global__ __launch_bounds__(RT_BLOCK) void accumulate_kernel(int n_pixel, int f
 // Pool entry: three 16-byte records.  A new path has only the first: its origin is the camera, its sample index follows from
 // its place in the refill, its throughput is 1 and its depth the full depth.
 #define RT_FRESH_PATH 0x40000000u   // in the pixel word: a path that has not been shaded yet
-#define RT_PIXEL_MASK 0x3FFFFFFFu
+#define RT_PIXEL_MASK 0x03FFFFFFu
+// in the pixel word, bits 26..29: this entry's ray is, bit for bit, the ray of the entry that many places before it in the
+// pool (another sample of the same pixel that left a mirror or a pane of glass the same way): it is not walked, and its
+// shading reads that entry's hit
+#define RT_SAME_RAY_SHIFT 26
+#define RT_SAME_RAY_MASK 0x3C000000u
 struct WfPools {
-    float4* p0[2];      // dir.xyz, pixel word: pixel | RT_FRESH_PATH, or -1 when there is nothing to trace
+    float4* p0[2];      // dir.xyz, pixel word: pixel | same-ray distance | RT_FRESH_PATH, or -1 when there is nothing to trace
     float4* p1[2];      // origin.xyz, sample (int bits); not stored for new paths
     float4* p2[2];      // color.rgb, depth left (int bits); not stored for new paths
     float4* hit;        // t, u, v, packed triangle (written by extend for the pool it ran on)
@@ -242,7 +247,9 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
     const uint32_t have = r < regions ? ctl->count[nxt][r * RT_QUEUE_STRIDE] : 0u;
     // a new entry takes `entry_yield` lanes of the shading launch and may leave as many survivors behind (one per sample
     // of its run), all in this region of the other pool: only as many entries are started as the region has room for that
-    const uint32_t room = r < regions ? (region_cap - have) / entry_yield : 0u;
+    // (the new entries' lanes start at a multiple of the run length, so that a run never straddles two waves of the shading launch)
+    const uint32_t have_up = (have + entry_yield - 1u) / entry_yield * entry_yield;
+    const uint32_t room = (r < regions && have_up < region_cap) ? (region_cap - have_up) / entry_yield : 0u;
     // exclusive prefix of the rooms: regions are filled in order until the paths run out
     auto exclusive = [&](uint32_t v) {
         scan[r] = v;
@@ -512,7 +519,8 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
             if (!(__float_as_uint(a.w) & RT_FRESH_PATH)) b = b1;
         }
         // entries with nothing to trace (lanes outside the image) carry -1: their hit stays "none"
-        const bool trace = take && (int)__float_as_uint(a.w) >= 0;
+        // ... and so do entries whose ray another entry walks (their shading reads that entry's hit)
+        const bool trace = take && (int)__float_as_uint(a.w) >= 0 && !(__float_as_uint(a.w) & RT_SAME_RAY_MASK);
         RayD rn;
         ray_set(rn, mk3(b.x, b.y, b.z), mk3(a.x, a.y, a.z));
         Hit hn;
@@ -626,32 +634,37 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int cur, uint32_t regions, uint32_t log2_region_cap,
-                                                                  PathParams pp) {
+                                                                  PathParams pp, int share_equal) {
     const uint32_t reg = blockIdx.x % regions, within = blockIdx.x / regions;
     const uint32_t local = within * RT_SHADE_BLOCK + threadIdx.x;          // lane's place among the region's lanes
     const uint32_t live = ctl->count[cur][reg * RT_QUEUE_STRIDE];
     const uint32_t continuing = ctl->gen_base[reg];                          // the new entries lie behind the continuing ones
-    const uint32_t lanes = continuing + (live - continuing) * (uint32_t)pp.run_lanes;
+    // the new entries' lanes start at a multiple of the run length (a power of two up to 64 then keeps a run inside one wave)
+    const uint32_t head = (continuing + (uint32_t)pp.run_lanes - 1u) / (uint32_t)pp.run_lanes * (uint32_t)pp.run_lanes;
+    const uint32_t lanes = head + (live - continuing) * (uint32_t)pp.run_lanes;
     if (within * RT_SHADE_BLOCK >= lanes) return;                            // nothing of this region is left for this workgroup
     const int nxt = cur ^ 1;
     uint32_t n_shaded = 0, n_tex = 0, n_paths = 0, n_rays = 0, n_walks = 0;
-    bool survives = false;
-    float4 o0, o1, o2;
-    if (local < lanes) {
+    bool survives = false, repeatable = false;
+    float4 o0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o1 = o0, o2 = o0;
+    if (local < continuing || (local >= head && local < lanes)) {
         uint32_t entry = local, nth = 0;                                     // pool entry of the region; sample of its run
-        if (local >= continuing) entry = continuing + udiv_by(local - continuing, (uint32_t)pp.run_lanes, pp.run_lanes_magic, nth);
+        if (local >= head) entry = continuing + udiv_by(local - head, (uint32_t)pp.run_lanes, pp.run_lanes_magic, nth);
         const uint32_t i = (reg << log2_region_cap) + entry;
         // a new entry: origin, throughput and depth are implied, and which run of samples it is follows from its place
         // in the refill, as wf_generate_kernel counted it out; any other path: second and third record.  Which of the two
         // an entry is follows from its place as well, so all of a path's records are asked for at once.
         float4 b = make_float4(pp.cam.pos[0], pp.cam.pos[1], pp.cam.pos[2], 0.0f);
         float4 c = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pp.max_depth));
-        const float4 a = pool_load(&pools.p0[cur][i]), hq = pool_load(&pools.hit[i]);
+        const float4 a = pool_load(&pools.p0[cur][i]);
+        float4 hq = pool_load(&pools.hit[i]);
         if (entry < continuing) {
             b = pool_load(&pools.p1[cur][i]);
             c = pool_load(&pools.p2[cur][i]);
         }
         const uint32_t word = __float_as_uint(a.w);
+        const uint32_t same_as = (int)word >= 0 ? (word & RT_SAME_RAY_MASK) >> RT_SAME_RAY_SHIFT : 0u;
+        if (same_as) hq = pool_load(&pools.hit[i - same_as]);       // the hit of the entry that walked this ray
         if ((int)word >= 0) {                                        // -1: nothing was traced for this entry
             const int pixel = (int)(word & RT_PIXEL_MASK);
             int sample, s_hi;
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
                 int depth = __float_as_int(c.w);
                 depth--;                                             // the segment extend just traced (raytrace.cu:213)
                 n_rays = 1;
-                n_walks = nth == 0 ? 1u : 0u;
+                n_walks = (nth == 0 && same_as == 0) ? 1u : 0u;
                 ShadeConst sk;
                 sk.ambient = mk3(pp.ambient[0], pp.ambient[1], pp.ambient[2]);
                 sk.rr = pp.rr; sk.k0 = pp.key0; sk.k1 = pp.key1;
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
                 h.t = hq.x; h.u = hq.y; h.v = hq.z; h.tri = __float_as_uint(hq.w);
                 v3 color = mk3(c.x, c.y, c.z);
                 const uint32_t bounce = (uint32_t)(pp.max_depth - 1 - depth);
-                bool finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex);
+                bool finished = shade_hit<COUNT>(sc, sk, ray, h, (uint32_t)pixel, (uint32_t)sample, bounce, color, n_shaded, n_tex, repeatable);
                 if (!finished && depth == 0) {
                     // the next `while (depth--)` test fails: out of depth, the path adds nothing (raytrace.cu:243)
                     finished = true;
@@ -701,11 +714,45 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     }
     const int lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(survives);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));      // survivors in the lanes before this one
+    // Samples that reached this hit along one ray and leave a mirror or a pane of glass the same way are, bit for bit, one
+    // ray again: only the first of them (the lowest lane) needs to be walked.  The samples of a pixel's batch lie in
+    // neighbouring lanes (they were filed together), so a lane looks at the 15 lanes before it, by a hash of pixel and
+    // ray first and then word for word; the others carry the distance to the first one's place in the pool.
+    const bool candidate = survives && repeatable && share_equal;
+    if (__any(candidate)) {
+        const uint32_t w[7] = {__float_as_uint(o0.w), __float_as_uint(o1.x), __float_as_uint(o1.y), __float_as_uint(o1.z),
+                               __float_as_uint(o0.x), __float_as_uint(o0.y), __float_as_uint(o0.z)};
+        uint32_t hash = w[0] * 0x9E3779B1u;
+#pragma unroll
+        for (int k = 1; k < 7; k++) hash = (hash ^ w[k]) * 0x85EBCA6Bu + (hash >> 15);
+        int back = 0;
+#pragma unroll
+        for (int s = 1; s <= 15; s++) {
+            const uint32_t their_hash = (uint32_t)__shfl_up((int)hash, s, 64);
+            const int theirs = __shfl_up((int)candidate, s, 64);
+            if (candidate && lane >= s && theirs && their_hash == hash) back = s;            // ends at the lowest lane that matches
+        }
+        int first = lane - back;
+        bool same = back != 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) same = same & ((uint32_t)__shfl((int)w[k], first, 64) == w[k]);
+        if (!same) first = lane;
+        // runs longer than 16 samples: the lane found may itself have found an earlier one
+        for (int hop = 0; hop < 4; hop++) {
+            const int further = __shfl(first, first, 64);
+            if (!__any(further != first)) break;
+            first = further;
+        }
+        const uint32_t distance = rank - (uint32_t)__shfl((int)rank, first, 64);
+        if (first != lane && distance >= 1u && distance <= (RT_SAME_RAY_MASK >> RT_SAME_RAY_SHIFT))
+            o0.w = __uint_as_float(__float_as_uint(o0.w) | (distance << RT_SAME_RAY_SHIFT));
+    }
     uint32_t base = 0;
     if (lane == 0 && m) base = atomicAdd(&ctl->count[nxt][reg * RT_QUEUE_STRIDE], (uint32_t)__popcll(m));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (survives) {
-        const uint32_t pos = (reg << log2_region_cap) + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t pos = (reg << log2_region_cap) + base + rank;
         pool_store(&pools.p0[nxt][pos], o0);
         pool_store(&pools.p1[nxt][pos], o1);
         pool_store(&pools.p2[nxt][pos], o2);
@@ -831,6 +878,7 @@ struct rt_context {
     int opt_hot_tune = 1;            // wavefront: number the node records by measured visits before a frame (one calibration sample per pixel)
     bool hot_dirty = true;           // scene or camera changed since the node numbering was last tuned
     void* d_tune = nullptr;          // calibration scratch: visit counts, throw-away counters, permutation, a copy of the candidate records
+    int opt_share_equal = 1;         // wavefront: samples of a pixel that leave a mirror or glass along one and the same ray share that ray's walk too
     int opt_share_primary = 1;       // wavefront: one closest-hit query per pixel and semantic batch (its samples share the primary ray)
     int opt_gpu_bvh = 0;             // 1 = rt_upload_scene builds its own tree on the device instead of re-packing the caller's
     int opt_lds_slots = 11;          // stack levels kept in LDS (deeper ones spill to private memory)
@@ -993,6 +1041,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_GPU_BVH: ctx->opt_gpu_bvh = value ? 1 : 0; return RT_OK;
     case RT_OPT_HOT_TUNE: ctx->opt_hot_tune = value ? 1 : 0; return RT_OK;
     case RT_OPT_SHARE_PRIMARY: ctx->opt_share_primary = value ? 1 : 0; return RT_OK;
+    case RT_OPT_SHARE_EQUAL: ctx->opt_share_equal = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
         if (value != 0 && value != 1) return fail(RT_ERR_INVALID, "rt_set_option: mode must be 0 (megakernel) or 1 (wavefront)");
         ctx->opt_mode = value; return RT_OK;
@@ -1313,8 +1362,8 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             const int nxt = R.cur ^ 1;
             if (R.iter > 0) {
                 const int tk = timing_begin(ctx, 1, ls);
-                if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
-                else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp);
+                if (ctx->opt_counters) hipLaunchKernelGGL(wf_shade_kernel<true>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp, ctx->opt_share_equal);
+                else hipLaunchKernelGGL(wf_shade_kernel<false>, sgrid, sblock, 0, ls, ctx->dev, L.d_ctl, L.pools, R.cur, regions, log2_region_cap, R.pp, ctx->opt_share_equal);
                 timing_end(ctx, tk, ls);
                 // iteration i traces segment i - j of the paths started in iteration j, so the shading of iteration
                 // (last start) + max_depth ends the pass's last paths
@@ -1435,7 +1484,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     if (first_sample % semantic_batch) return fail(RT_ERR_INVALID, name + ": first_sample must be a multiple of semantic_batch");
     if ((long long)first_sample + spp > 0x7FFFFFFFLL - semantic_batch) return fail(RT_ERR_INVALID, name + ": sample index overflow");
     if (spp == 0) return RT_OK;
-    if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, name + ": more than 2^30-1 pixels");
+    if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, name + ": more than 2^26-1 pixels");
     if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, name + ": BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
     // slot buffer: one float3 per (sample of the pass, pixel), then one carry plane

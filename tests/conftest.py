@@ -25,5 +25,6 @@ def gpu_ctx():
     # one closest-hit walk per sample, as upstream executes it: the tests compare box and triangle test counts with the
     # oracle's; the shared first walk has tests of its own
     ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+    ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
     yield ctx
     ctx.close()

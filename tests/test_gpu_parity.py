@@ -583,13 +583,20 @@ def test_shared_primary_walk_bit_exact(gpu_ctx, name, kw, first, n, batch, cap, 
     try:
         got, gcnt = p.gpu_render(first, n, batch)
         again, _ = p.gpu_render(first, n, batch)
+        # ... and with the walks of continued paths shared where their rays coincide (mirrors, glass)
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 1)
+        both, bcnt = p.gpu_render(first, n, batch)
     finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
         gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
         gpu_ctx.set_option(capi.OPT_WF_LANES, 1)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
         gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
     assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
     assert same_f32(again, ref)
+    assert same_f32(both, ref), f"{(bits(both) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ with equal rays shared"
+    assert bcnt[capi.CNT_RAYS] == rcnt[0] and bcnt[capi.CNT_SHADED] == rcnt[3] and bcnt[capi.CNT_TEX_FETCHES] == rcnt[4]
+    assert bcnt[capi.CNT_WALKS] <= gcnt[capi.CNT_WALKS]
     npix = p.cfg.width * p.cfg.height
     assert gcnt[capi.CNT_RAYS] == rcnt[0]
     assert gcnt[capi.CNT_SHADED] == rcnt[3] and gcnt[capi.CNT_TEX_FETCHES] == rcnt[4]
@@ -601,3 +608,29 @@ def test_shared_primary_walk_bit_exact(gpu_ctx, name, kw, first, n, batch, cap, 
         assert gcnt[capi.CNT_WALKS] < rcnt[0]            # how the pipelines cut the samples is theirs to choose
     else:
         assert gcnt[capi.CNT_WALKS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2]
+
+
+def test_equal_rays_share_a_walk_in_a_glass_scene(gpu_ctx):
+    """RT_OPT_SHARE_EQUAL on the all-glass car: after the shared first hit most samples of a batch refract the same way and
+    are one ray again, bounce after bounce.  The image and the per-sample counts are the oracle's, the walks far fewer."""
+    p = Pair(gpu_ctx, scene.formula1(width=128, height=80, n_samples=32, detail=0.05, glass=True))
+    ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, 16), 0, 32)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 17)
+    gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+    try:
+        first_only, c1 = p.gpu_render(0, 32, 16)
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 1)
+        got, c2 = p.gpu_render(0, 32, 16)
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)             # equal rays can also be shared without the shared first walk
+        alone, c3 = p.gpu_render(0, 32, 16)
+    finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(first_only, ref) and same_f32(got, ref) and same_f32(alone, ref)
+    for c in (c1, c2, c3):
+        assert c[capi.CNT_RAYS] == rcnt[0] and c[capi.CNT_SHADED] == rcnt[3] and c[capi.CNT_PATHS] == 128 * 80 * 32
+    print(f"walks per upstream ray: first walk shared {c1[capi.CNT_WALKS] / rcnt[0]:.3f}, equal rays too {c2[capi.CNT_WALKS] / rcnt[0]:.3f}, equal rays only {c3[capi.CNT_WALKS] / rcnt[0]:.3f}")
+    assert c2[capi.CNT_WALKS] < 0.8 * c1[capi.CNT_WALKS] and c3[capi.CNT_WALKS] < rcnt[0]
