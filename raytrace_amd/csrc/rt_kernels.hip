@@ -640,7 +640,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
     const uint32_t live = ctl->count[cur][reg * RT_QUEUE_STRIDE];
     const uint32_t continuing = ctl->gen_base[reg];                          // the new entries lie behind the continuing ones
     // the new entries' lanes start at a multiple of the run length (a power of two up to 64 then keeps a run inside one wave)
-    const uint32_t head = (continuing + (uint32_t)pp.run_lanes - 1u) / (uint32_t)pp.run_lanes * (uint32_t)pp.run_lanes;
+    uint32_t over;
+    (void)udiv_by(continuing, (uint32_t)pp.run_lanes, pp.run_lanes_magic, over);
+    const uint32_t head = over ? continuing + (uint32_t)pp.run_lanes - over : continuing;
     const uint32_t lanes = head + (live - continuing) * (uint32_t)pp.run_lanes;
     if (within * RT_SHADE_BLOCK >= lanes) return;                            // nothing of this region is left for this workgroup
     const int nxt = cur ^ 1;
