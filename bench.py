@@ -361,7 +361,7 @@ def main():
         ctx.set_option(capi.OPT_SHARE_EQUAL, share_equal)
         accum.zero_()
         sh_ms = sh["elapsed"] * 1e3 / max(1, args.steps)
-        shared_line = {"option": "RT_OPT_SHARE_PRIMARY = 1 (library default): one closest-hit walk per pixel and semantic batch, same image bit for bit",
+        shared_line = {"option": "RT_OPT_SHARE_PRIMARY = 1, RT_OPT_SHARE_EQUAL = 1 (library defaults): rays that coincide bit for bit are walked once -- the first walk of a semantic batch, continued paths that leave a mirror or glass the same way; same image bit for bit",
                        "ms_per_step": round(sh_ms, 3),
                        "seconds_per_frame": round(sh_ms * 1e-3 * frame_spp / (spp * world), 3),
                        "upstream_rays_mrays_per_s": round(sh["rays"] / sh["elapsed"] / 1e6, 2),
@@ -418,7 +418,7 @@ def main():
             top = max(roofs, key=roofs.get)
             binding = {"roof": top, "frac": roofs[top], "all": roofs, "wave_cycle_split": kp.get("wave_cycle_split"),
                        "resident_waves_mean": kp.get("mean_waves_in_flight"), "resident_wave_limit": kp.get("resident_wave_limit")}
-        what = "closest-hit queries as upstream counts them; the first walk of a semantic batch is shared" if args.share_primary == 1 else "closest-hit queries"
+        what = "closest-hit queries as upstream counts them; coinciding rays are walked once" if args.share_primary == 1 else "closest-hit queries"
         out = {
             "metric": f"Mrays/s ({what}), formula1 2000x1200 8192spp depth8" if args.scene == "formula1" and (cfg.width, cfg.height) == (2000, 1200)
                       else f"Mrays/s ({what}), {args.scene} {cfg.width}x{cfg.height} {frame_spp}spp depth{cfg.max_depth}",
@@ -505,7 +505,7 @@ def device_tree_line(args, asm, cfg, objs, device_index, spp, frame_spp):
         dt = time.perf_counter() - t0
         cnt = ctx.counters()
         ms = dt * 1e3 / max(1, args.steps)
-        return {"option": "RT_OPT_GPU_BVH = 1 and RT_OPT_SHARE_PRIMARY = 1: tree built on the device by agglomeration, first walk of a batch shared",
+        return {"option": "RT_OPT_GPU_BVH = 1 with the library's defaults otherwise: tree built on the device by agglomeration, coinciding rays walked once",
                 "ms_per_step": round(ms, 3), "seconds_per_frame": round(ms * 1e-3 * frame_spp / spp, 3),
                 "upstream_rays_mrays_per_s": round(cnt[capi.CNT_RAYS] / dt / 1e6, 2),
                 "walks_executed_mrays_per_s": round(cnt[capi.CNT_WALKS] / dt / 1e6, 2),
