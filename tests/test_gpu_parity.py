@@ -251,11 +251,14 @@ def test_wavefront_scheduling_knobs_do_not_change_the_image(gpu_ctx):
             assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_TRI_TESTS] == rcnt[2], (sort, hot, burst, run, vote, refill, block)
             # the same schedule with the first walk of a batch shared: same image, same rays, fewer walks
             gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 1)
+            gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 1)
             got, gcnt = p.gpu_render(0, 8, 4)
+            gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
             gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
             assert same_f32(got, ref), ("shared", sort, hot, burst, run, vote, refill, block)
             assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_WALKS] < rcnt[0] and gcnt[capi.CNT_SHADED] == rcnt[3]
     finally:
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
         gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
         gpu_ctx.set_option(capi.OPT_WF_SORT, 1)
         gpu_ctx.set_option(capi.OPT_WF_VOTE, 32)
