@@ -137,8 +137,8 @@ enum {
     RT_OPT_WF_CAPACITY_LOG2 = 7, /* wavefront pool size = at most 2^value paths (default 27; 7 * 16 bytes of HBM per path, 15 GB at the default), never more
                                  than a pass has paths; a long closest-hit launch hides the wait for its last long rays better than a short one */
     RT_OPT_WF_RUN = 8,        /* wavefront: pool entries a closest-hit wave claims from the queue at a time (default 256, >= 64); scheduling only */
-    RT_OPT_WF_SORT = 10,      /* wavefront: 1 = each shading workgroup files its surviving rays by direction octant (default), 0 = plain order;
-                                 scheduling only */
+    RT_OPT_WF_SORT = 10,      /* accepted and ignored (an earlier shading kernel filed its survivors by direction octant; the present one
+                                 files them in lane order, which keeps the samples of a pixel next to each other) */
     RT_OPT_TIMING = 11,       /* 1 = bracket every traversal kernel launch with HIP events on the launch stream (see rt_get_timing) */
     RT_OPT_HOT_NODES = 12,    /* wavefront: node records nearest to the root that the closest-hit kernel copies to LDS (default 100, 0..512) */
     RT_OPT_WF_VOTE = 13,      /* wavefront closest-hit: 0 = fixed pattern (RT_OPT_WF_BURST node trips, then one leaf trip); k > 0 (default 32) = every trip
