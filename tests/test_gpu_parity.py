@@ -572,6 +572,9 @@ def _runs(first, n, batch):
     ("formula1", dict(width=96, height=60, n_samples=16, detail=0.05, tex_size=64), 0, 16, 4, 14, 2, True),    # two pipelines split the samples
     ("room", dict(width=60, height=40, n_samples=8, detail=0.2, tex_size=64), 0, 8, 4, 13, 1, True),          # 16 bounces, camera inside
     ("shuttle", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=64), 0, 8, 1, 12, 1, False),      # batch of one: nothing to share
+    ("bunny", dict(width=64, height=64, n_samples=16, bunny_tris=8000), 0, 16, 16, 16, 1, True),               # rough and smooth metal: the smooth one reflects all samples alike
+    ("house", dict(width=64, height=64, n_samples=8, detail=0.05, tex_size=64), 0, 8, 8, 14, 1, True),
+    ("bike", dict(width=80, height=60, n_samples=8, detail=0.05, tex_size=64), 0, 8, 4, 15, 2, True),
 ])
 def test_shared_primary_walk_bit_exact(gpu_ctx, name, kw, first, n, batch, cap, lanes, shared):
     """RT_OPT_SHARE_PRIMARY: the samples of a semantic batch start with one and the same primary ray
