@@ -233,7 +233,8 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
  * live in a static device array of RT_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process
  * ends, every pass is one launch of the megakernel design whatever RT_OPT_MODE says, and no timing events are recorded.
  * The frame must fit twice: 2 * n_pixel * 12 bytes <= RT_STATIC_SCRATCH_BYTES (2 796 202 pixels), else RT_ERR_CAPACITY;
- * samples per pass = what fits (27 at 2000x1200).  All contexts of a device share that device's array and a call
+ * samples per pass = floor(RT_STATIC_SCRATCH_BYTES / (12 * n_pixel)) - 1 (one plane is the carry): 1 at 2000x1200, 57 at
+ * 400x240.  All contexts of a device share that device's array and a call
  * leaves its slots behind: every slot and the carry plane are written before they are read, so nothing needs clearing,
  * but two calls that overlap in time on one GPU (two streams, two threads, two contexts) race.  Asynchronous on `stream`. */
 #define RT_STATIC_SCRATCH_BYTES (64u << 20)
@@ -271,6 +272,14 @@ int rt_get_timing(rt_context* ctx, double out[8]);
  * [6]=microseconds the copy of the triangle arrays to the device took, [7]=levels of the binary hierarchy. */
 int rt_scene_stats(rt_context* ctx, uint64_t out[8]);
 
+/* Test aid, no upstream counterpart: reads the packed node records back and checks what the renumbering of the
+ * LDS candidates (RT_OPT_HOT_TUNE) relies on.  out[0] = node records, out[1] = k = the records that may be renumbered
+ * (the first min(4096, out[0])), out[2] = references held by a record >= k to a record < k (must be 0: such a
+ * reference would not follow a renumbering), out[3] = references to a record number >= out[0] (must be 0),
+ * out[4] = inner references to a record whose number is not above the referring record's (must be 0: parents carry
+ * lower numbers than their children).  Copies the whole node array to the host: for tests on small scenes. */
+int rt_check_node_numbering(rt_context* ctx, uint64_t out[8]);
+
 /* ---- multi-GPU: sample split and the sum onto the root GPU ----
  * No upstream counterpart (upstream is single-GPU, no collective anywhere).  The frame splits where upstream's batch
  * loop runs (csrc/worker.cpp:71-91): batches are independent, so each GPU traces a contiguous run of whole batches of
@@ -289,7 +298,8 @@ typedef struct rt_group rt_group;
 int rt_group_unique_id(uint8_t id[RT_GROUP_ID_BYTES]);
 /* The contexts this process drives (n_local >= 1; one host thread per GPU, or one process per GPU with n_local = 1).
  * Their distinct devices take RCCL ranks first_rank, first_rank + 1, ... of a communicator of `world` ranks; contexts
- * that share a device share its rank.  id = null: the world is this process alone (ncclCommInitAll). */
+ * that share a device share its rank.  id = null: the world is this process alone (ncclCommInitAll), first_rank must
+ * then be 0. */
 int rt_group_create(rt_context* const* ctxs, int n_local, int first_rank, int world, const uint8_t* id, rt_group** out);
 int rt_group_destroy(rt_group* group);
 /* Adds up d_buffers[k] (device, `count` floats, k-th context of rt_group_create, its work queued on streams[k]; streams

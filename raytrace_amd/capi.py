@@ -65,7 +65,7 @@ class RtTransform(C.Structure):
 EXPORTS = [
     "rt_last_error", "rt_abi_version", "rt_build_bvh", "rt_apply_transform", "rt_create", "rt_destroy", "rt_set_option",
     "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_raytrace_static", "rt_post_process", "rt_primary_rays",
-    "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_device_alloc", "rt_device_free",
+    "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_check_node_numbering", "rt_device_alloc", "rt_device_free",
     "rt_device_zero", "rt_copy_to_host", "rt_copy_to_device", "rt_synchronize",
     "rt_get_device", "rt_partition_samples", "rt_group_unique_id", "rt_group_create", "rt_group_destroy", "rt_reduce_to_root",
 ]
@@ -112,6 +112,7 @@ def load():
         "rt_reset_counters": [vp],
         "rt_get_timing": [vp, C.POINTER(C.c_double)],
         "rt_scene_stats": [vp, C.POINTER(u64)],
+        "rt_check_node_numbering": [vp, C.POINTER(u64)],
         "rt_device_alloc": [vp, u64, C.POINTER(vp)],
         "rt_device_free": [vp, vp],
         "rt_device_zero": [vp, vp, u64, vp],
@@ -258,6 +259,12 @@ class Context:
         check(self.lib.rt_scene_stats(self.h, out))
         return {"triangles": out[0], "inner_nodes": out[1], "stack_slots": out[2], "device_bytes": out[3], "objects": out[4],
                 "gpu_build_ms": out[5] / 1000.0, "gpu_copy_ms": out[6] / 1000.0, "gpu_binary_levels": out[7]}
+
+    def check_node_numbering(self):
+        out = (C.c_uint64 * 8)()
+        check(self.lib.rt_check_node_numbering(self.h, out))
+        return {"records": out[0], "candidates": out[1], "refs_into_candidates_from_behind": out[2], "refs_out_of_range": out[3],
+                "refs_not_ascending": out[4]}
 
     def synchronize(self):
         check(self.lib.rt_synchronize(self.h))

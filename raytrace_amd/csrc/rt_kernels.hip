@@ -919,6 +919,7 @@ struct rt_context {
     int lanes_allocated = 0;
     int opt_wf_lanes = 1;            // pipelines per pass (2 measured slower: the second pipeline's shading starves behind the first's closest-hit launch)
     uint32_t pool_capacity = 0;
+    uint32_t pool_cap_limit = 0xFFFFFFFFu;   // the largest pool this device had memory for, once an allocation has failed
     float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
     int stack_slots = 1;
@@ -1194,11 +1195,14 @@ int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera
     if (!ctx || width <= 0 || height <= 0 || !camera_pos || !camera_dir || !camera_up)
         return fail(RT_ERR_INVALID, "rt_setup_raytrace: bad argument");
     if ((long long)width * height > 0x7FFFFFFFLL / 6) return fail(RT_ERR_INVALID, "rt_setup_raytrace: frame too large");
-    ctx->cam = camera_frame(width, height, camera_pos, camera_dir, camera_up, fov_radians);
+    const CameraFrame frame = camera_frame(width, height, camera_pos, camera_dir, camera_up, fov_radians);
+    // the node numbering was tuned for a view: only another view asks for another calibration pass (a worker sets the
+    // same camera again before every frame)
+    if (!ctx->have_camera || std::memcmp(&frame, &ctx->cam, sizeof frame) != 0) ctx->hot_dirty = true;
+    ctx->cam = frame;
     ctx->width = width;
     ctx->height = height;
     ctx->have_camera = true;
-    ctx->hot_dirty = true;
     return RT_OK;
 }
 
@@ -1261,6 +1265,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     const unsigned long long pass_paths = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
     uint32_t cap = 1u << ctx->opt_wf_log2;
     while (cap > (1u << 16) && (unsigned long long)(cap >> 1) >= pass_paths) cap >>= 1;
+    cap = std::min(cap, ctx->pool_cap_limit);    // a size that failed once is not tried again on every pass
     if (ctx->pool_capacity < cap || ctx->lanes_allocated < n_lanes) {
         HIP_TRY(hipStreamSynchronize(s));
         // a device with less free memory than the default pool takes (15 GB) gets a smaller pool, not an error
@@ -1286,6 +1291,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
             free_pools(ctx);
             if (e != hipErrorOutOfMemory || cap <= (1u << 16)) return fail(RT_ERR_DEVICE, std::string("rt_raytrace: path pools: ") + hipGetErrorString(e));
             cap >>= 1;
+            ctx->pool_cap_limit = cap;
         }
         ctx->lanes_allocated = n_lanes;
         ctx->pool_capacity = cap;
@@ -1656,6 +1662,28 @@ int rt_scene_stats(rt_context* ctx, uint64_t out[8]) {
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_scene_stats: null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_scene_stats: no scene uploaded");
     std::memcpy(out, ctx->stats, sizeof(ctx->stats));
+    return RT_OK;
+}
+
+int rt_check_node_numbering(rt_context* ctx, uint64_t out[8]) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_check_node_numbering: null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_check_node_numbering: no scene uploaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint64_t n = ctx->stats[1];
+    std::vector<Node4> nodes(n);
+    if (n) HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, n * sizeof(Node4), hipMemcpyDeviceToHost));
+    const uint64_t k = std::min<uint64_t>(RT_HIST_NODES, n);
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = n; out[1] = k;
+    for (uint64_t i = 0; i < n; i++)
+        for (int slot = 0; slot < 4; slot++) {
+            const uint32_t r = nodes[i].ref[slot];
+            if (r == REF_NONE || (r & REF_LEAF)) continue;
+            if (i >= k && r < k) out[2]++;
+            if (r >= n) out[3]++;
+            if (r <= i) out[4]++;
+        }
     return RT_OK;
 }
 

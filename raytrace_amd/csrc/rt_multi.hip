@@ -135,6 +135,8 @@ int rt_group_create(rt_context* const* ctxs, int n_local, int first_rank, int wo
     }
     const int n_dev = (int)g->devices.size();
     if (first_rank + n_dev > world) { delete g; return fail(RT_ERR_INVALID, "rt_group_create: more local devices than ranks left in the world"); }
+    // without an id the communicator is made by ncclCommInitAll, which numbers this process's devices from rank 0
+    if (!id && first_rank != 0) { delete g; return fail(RT_ERR_INVALID, "rt_group_create: first_rank must be 0 when the world lives in one process (no id)"); }
     if (!id && n_dev != world) { delete g; return fail(RT_ERR_INVALID, "rt_group_create: a world that spans processes needs the id of rt_group_unique_id"); }
     for (rt_group::Member& m : g->members) {
         hipError_t e = hipSetDevice(m.device);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <thread>
 
 namespace rth {
 
@@ -147,11 +148,24 @@ bool HttpServer::serve(const std::string& address, int port) {
         if (ready <= 0) continue;
         const int client = ::accept(fd, nullptr, nullptr);
         if (client < 0) continue;
-        converse(client);
-        ::shutdown(client, SHUT_RDWR);
-        ::close(client);
+        // Every connection gets a short-lived thread of its own, so a client that connects and then sends nothing (it is
+        // given five seconds) holds up nobody else's request.  Beyond kMaxConversations at once the accept loop answers
+        // the connection itself, which bounds the threads a flood of connections can start.
+        auto talk = [this, client] {
+            converse(client);
+            ::shutdown(client, SHUT_RDWR);
+            ::close(client);
+        };
+        if (conversations_.fetch_add(1) < kMaxConversations) {
+            std::thread([this, talk] { talk(); conversations_.fetch_sub(1); }).detach();
+        } else {
+            talk();
+            conversations_.fetch_sub(1);
+        }
     }
     ::close(fd);
+    // the detached threads use this object: wait for the last of them (each ends within its receive timeout)
+    while (conversations_.load() > 0) ::usleep(10000);
     return true;
 }
 

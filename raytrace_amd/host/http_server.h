@@ -2,7 +2,8 @@
 //
 // Upstream uses cpp-httplib (third/httplib.h) for six routes and one static directory (csrc/server.cpp:36-113).
 // This server handles one request per connection ("Connection: close"), GET and POST with Content-Length, a table of
-// exact (method, path) routes, and GET of plain files below one directory.
+// exact (method, path) routes, and GET of plain files below one directory.  Connections are answered concurrently (a
+// thread per connection, as cpp-httplib's pool does): routes must be safe to call from several threads at once.
 #ifndef RT_HTTP_SERVER_H
 #define RT_HTTP_SERVER_H
 
@@ -39,6 +40,8 @@ private:
     std::vector<Entry> table_;
     std::string directory_;
     std::atomic_bool stopping_{false};
+    std::atomic_int conversations_{0};                    // connections being answered right now
+    static const int kMaxConversations = 32;
 
     HttpReply answer(const HttpRequest& request) const;
     void converse(int fd) const;

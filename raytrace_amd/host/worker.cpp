@@ -249,11 +249,13 @@ void Worker::write_frames() {
     const std::string path = output_dir_ + "/" + scene_name_ + "-output.png";
     for (;;) {
         int width, height;
+        long seen;                                      // the frame this turn encodes: `traced` as it stood when `newest` was copied
         {
             std::unique_lock<std::mutex> hold(shared_.lock);
             shared_.changed.wait(hold, [this] { return shared_.traced > shared_.written || (shared_.quitting && !shared_.frame_wanted); });
             if (shared_.traced == shared_.written) break;
             frame = shared_.newest;
+            seen = shared_.traced;
             width = scene_.config().width;
             height = scene_.config().height;
         }
@@ -268,7 +270,8 @@ void Worker::write_frames() {
         else std::cerr << "Cannot save image: " << error << std::endl;
         std::lock_guard<std::mutex> hold(shared_.lock);
         if (saved) shared_.png_path = path;
-        shared_.written = shared_.traced;
+        // a frame published while this one was being encoded stays unwritten, so the wait above fires again for it
+        shared_.written = seen;
     }
     std::cout << "encoder: cleaning up" << std::endl;
 }

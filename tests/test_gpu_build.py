@@ -232,3 +232,56 @@ def test_device_build_falls_back_when_the_agglomeration_crawls(capfd):
         assert (bits(t) == bits(brute)).mean() > 0.995 and (t >= brute).all() and np.isfinite(t).mean() > 0.5
     finally:
         ctx.close()
+
+
+def test_hot_node_tuning_on_a_device_built_tree_moves_records_not_results():
+    """RT_OPT_GPU_BVH with RT_OPT_HOT_TUNE 0 and 1 at 64 spp (the calibration only runs from 64 samples per call on): the
+    renumbering of the LDS candidates must leave a device-built tree's results alone -- same buffer bit for bit, same
+    counts, the same closest-hit records before and after the renumbering -- and its premise is checked on the records
+    themselves: parents carry lower numbers than their children, so no record behind the candidates refers into them."""
+    import torch
+    asm = scene.formula1(width=200, height=120, n_samples=64, detail=0.15, tex_size=64)
+    cfg = asm.config
+    objs = scene.finalize(asm)
+    rays = np.concatenate([orc.primary_rays(orc.make_params(cfg, SEED, 16), 0)[::2], random_rays(np.random.RandomState(5), 8000, -150.0, 150.0)])
+    npix = cfg.width * cfg.height
+    out = {}
+    for tune in (0, 1):
+        ctx = capi.Context(0)
+        try:
+            ctx.set_option(capi.OPT_GPU_BVH, 1)
+            ctx.set_option(capi.OPT_HOT_TUNE, tune)
+            ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 18)
+            ctx.upload_scene([(t, None) for t, _ in objs], asm.materials, asm.textures)
+            ctx.init_randstate(SEED, cfg.width, cfg.height)
+            ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+            order = ctx.check_node_numbering()
+            assert order["records"] > order["candidates"] == 4096, order          # the tree is larger than the candidate set: the premise matters
+            assert order["refs_into_candidates_from_behind"] == 0 and order["refs_out_of_range"] == 0 and order["refs_not_ascending"] == 0, order
+            before = _hits(ctx, rays)
+            d = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.set_option(capi.OPT_COUNTERS, 1)
+            ctx.reset_counters()
+            ctx.raytrace(npix, 0, 64, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+            cnt = ctx.counters()
+            after = _hits(ctx, rays)                                              # on the renumbered records when tune == 1
+            for a, b in zip(before, after):
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+            order = ctx.check_node_numbering()
+            assert order["refs_into_candidates_from_behind"] == 0 and order["refs_out_of_range"] == 0, order
+            out[tune] = (d.cpu().numpy(), cnt, before)
+        finally:
+            ctx.close()
+    (a, ca, ha), (b, cb, hb) = out[0], out[1]
+    assert same_f32(a, b), f"{(bits(a) != bits(b)).any(axis=1).sum()} pixels differ between tuned and untuned numbering"
+    for k in (capi.CNT_RAYS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS):
+        assert ca[k] == cb[k], k
+    # Which continued rays are found to coincide (RT_OPT_SHARE_EQUAL looks at the 15 lanes before a survivor) depends on
+    # how the waves' compaction atomics happened to be ordered, so the walks run -- and the tests inside them -- may
+    # differ by a handful from one render to the next; the rays they answer do not.
+    for k in (capi.CNT_WALKS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_NODE_VISITS):
+        assert abs(ca[k] - cb[k]) <= 1e-3 * ca[k], k
+    assert cb[capi.CNT_HOT_VISITS] > 1.02 * ca[capi.CNT_HOT_VISITS]               # the calibration did run and did move records
+    for x, y in zip(ha, hb):                                                      # two builds of the same scene answer alike (numbers are addresses)
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)

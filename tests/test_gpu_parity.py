@@ -556,6 +556,46 @@ def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
     assert cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
 
 
+def test_library_defaults_all_at_once_against_the_oracle():
+    """A context with NOTHING set -- wavefront pipeline, first walk of a batch shared, coinciding continued rays shared,
+    LDS node records chosen by the calibration pass (64 spp is where it starts), default pool size -- on the
+    benchmark scene at full detail, 400x240, 64 spp in batches of 16: the whole buffer and every per-sample count against
+    the oracle's render.  Every knob has a test of its own; this is their conjunction, as a user of the library gets it."""
+    torch = _torch()
+    asm = scene.formula1(width=400, height=240, n_samples=64)
+    cfg = asm.config
+    objs = scene.finalize(asm)
+    ref, rcnt = orc.Scene(objs, asm.materials, asm.textures).render(orc.make_params(cfg, SEED, 16), 0, 64)
+    ctx = capi.Context(0)
+    try:
+        ctx.upload_scene(objs, asm.materials, asm.textures)
+        ctx.init_randstate(SEED, cfg.width, cfg.height)
+        ctx.setup_raytrace(cfg.width, cfg.height, cfg.camera_pos, cfg.camera_dir, cfg.camera_up, cfg.fov)
+        npix = cfg.width * cfg.height
+        d = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.raytrace(npix, 0, 64, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+        cnt = ctx.counters()                                        # the counters every build keeps: rays, paths, walks
+        got = d.cpu().numpy()
+        # the same call again with the counting build (the only option touched), into a fresh buffer
+        ctx.set_option(capi.OPT_COUNTERS, 1)
+        ctx.reset_counters()
+        d.zero_()
+        torch.cuda.synchronize()
+        ctx.raytrace(npix, 0, 64, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+        ccnt = ctx.counters()
+        counted = d.cpu().numpy()
+    finally:
+        ctx.close()
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert same_f32(counted, ref)
+    assert cnt[capi.CNT_RAYS] == rcnt[0] and cnt[capi.CNT_PATHS] == npix * 64
+    assert ccnt[capi.CNT_RAYS] == rcnt[0] and ccnt[capi.CNT_SHADED] == rcnt[3] and ccnt[capi.CNT_TEX_FETCHES] == rcnt[4]
+    # four batches of 16: at least the fifteen repeated first walks of every batch are saved, coinciding continued rays on top
+    assert cnt[capi.CNT_WALKS] <= rcnt[0] - npix * 64 + npix * 4 and abs(cnt[capi.CNT_WALKS] - ccnt[capi.CNT_WALKS]) <= 1e-3 * cnt[capi.CNT_WALKS]
+    assert ccnt[capi.CNT_HOT_VISITS] > 0
+
+
 def _runs(first, n, batch):
     """Semantic batches the samples [first, first + n) touch: one shared walk each."""
     return (first + n - 1) // batch - first // batch + 1 if n > 0 else 0
