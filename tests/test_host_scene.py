@@ -258,26 +258,13 @@ def summary(stdout):
     return rows
 
 
-@pytest.mark.parametrize("name,kw", [
-    ("material_box", dict(width=32, height=20, n_samples=8)),                                   # textured MTL record, every material type
-    ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=32)),             # 31 shapes, 10 MTL records, 4 textures
-    ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, glass=True)),              # simple_material
-    ("shuttle", dict(width=64, height=40, n_samples=4, detail=0.05, tex_size=32)),
-    ("luyu", dict(width=64, height=40, n_samples=4, statue_tris=3000)),
-    ("bike", dict(width=64, height=48, n_samples=4, detail=0.03, tex_size=16)),                 # fitted model far from the origin
-    ("bunny", dict(width=48, height=48, n_samples=4, bunny_tris=2000)),                         # scale 50 on a 0.15-unit mesh
-    ("cat", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),
-    ("house", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),                # planes scaled by 1e6
-    ("room", dict(width=48, height=32, n_samples=4, detail=0.1, tex_size=16)),                  # y-up camera, depth 16
-])
-def test_scene_loader_matches_python_assembly(tmp_path, name, kw):
-    asm = getattr(scene, name)(**kw)
-    path = scene_files.write_scene(asm, str(tmp_path / "files"))
-    r, out = load_with_cpp(path, tmp_path)
-    assert r.returncode == 0, r.stderr[-2000:]
-    s = summary(r.stdout)
+def assert_loader_output_matches(asm, stdout, out, size_and_spp=None):
+    """What bin/scene_dump printed and wrote for a scene file against the Python assembly of the same scene, array for
+    array.  `size_and_spp` = (width, height, n_samples) the file states, when they are not the assembly's."""
+    s = summary(stdout)
     cfg = asm.config
-    assert [int(s["config"][i]) for i in (1, 3, 5, 6, 8)] == [cfg.max_depth, 1000000, cfg.width, cfg.height, cfg.n_samples]
+    width, height, n_samples = size_and_spp or (cfg.width, cfg.height, cfg.n_samples)
+    assert [int(s["config"][i]) for i in (1, 3, 5, 6, 8)] == [cfg.max_depth, 1000000, width, height, n_samples]
     assert float.fromhex(s["config"][10]) == cfg.fov                                           # degrees -> radians as sceneloader.cpp:287
     assert same_f32(np.array([float.fromhex(s["config"][12]), float.fromhex(s["config"][14])], dtype=np.float32),
                     np.array([cfg.gamma, cfg.russian_roulette], dtype=np.float32))
@@ -300,6 +287,26 @@ def test_scene_loader_matches_python_assembly(tmp_path, name, kw):
     for i, tex in enumerate(asm.textures):
         got = np.fromfile(str(out / f"tex{i}.bin"), dtype=np.uint8).reshape(tex.shape)
         assert np.array_equal(got[:, :, :3], tex[:, :, :3]) and (got[:, :, 3] == 255).all()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("material_box", dict(width=32, height=20, n_samples=8)),                                   # textured MTL record, every material type
+    ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, tex_size=32)),             # 31 shapes, 10 MTL records, 4 textures
+    ("formula1", dict(width=96, height=60, n_samples=8, detail=0.05, glass=True)),              # simple_material
+    ("shuttle", dict(width=64, height=40, n_samples=4, detail=0.05, tex_size=32)),
+    ("luyu", dict(width=64, height=40, n_samples=4, statue_tris=3000)),
+    ("bike", dict(width=64, height=48, n_samples=4, detail=0.03, tex_size=16)),                 # fitted model far from the origin
+    ("bunny", dict(width=48, height=48, n_samples=4, bunny_tris=2000)),                         # scale 50 on a 0.15-unit mesh
+    ("cat", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),
+    ("house", dict(width=48, height=48, n_samples=4, detail=0.03, tex_size=16)),                # planes scaled by 1e6
+    ("room", dict(width=48, height=32, n_samples=4, detail=0.1, tex_size=16)),                  # y-up camera, depth 16
+])
+def test_scene_loader_matches_python_assembly(tmp_path, name, kw):
+    asm = getattr(scene, name)(**kw)
+    path = scene_files.write_scene(asm, str(tmp_path / "files"))
+    r, out = load_with_cpp(path, tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert_loader_output_matches(asm, r.stdout, out)
 
 
 BASE = """scene_config
