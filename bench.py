@@ -409,6 +409,18 @@ def main():
         traffic = kp.get("hbm_bytes_per_launch")
         # the counter passes ran the same command; their launch time (profiled clocks run ~3 % lower) prices their bytes
         traffic_gbps = traffic / (kp["kernel_ms_mean"] * 1e-3) / 1e9 if traffic and kp.get("kernel_ms_mean") else None
+        # the survey's per-ray figure (box and triangle reads of the walk, shading records and texels of the hits): what the
+        # path asks of the memory hierarchy, priced against HBM although LDS, L1, L2 and Infinity Cache serve nearly all of it
+        survey_gbps = walks_per_launch * bytes_per_ray / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        other_workloads = {}
+        if pmc_source and not pmc_source.startswith("none"):
+            try:
+                doc = json.load(open(os.path.join(ROOT, pmc_source)))
+                for wk, wv in doc.get("workloads", {}).items():
+                    if wk != workload_key(args, cfg) and "three_fractions" in wv:
+                        other_workloads[wk] = wv["three_fractions"]
+            except Exception:
+                pass
         binding = None
         if kp.get("valu_issue_frac") is not None:
             roofs = {"vector-instruction issue (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles)": kp.get("valu_issue_frac"),
@@ -447,6 +459,17 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes_per_launch), "rays_per_launch": round(rays_per_launch, 1), "walks_per_launch": round(walks_per_launch, 1),
                          "demand_bytes_per_ray": round(demand_bytes_per_ray, 1),
                          "demand_note": "32*box_tests + 36*triangle_tests per ray: requested of LDS/L1/L2/Infinity Cache, not of HBM",
+                         "survey_bytes_per_ray": round(bytes_per_ray, 1),
+                         "survey_formula": "32*box_tests + 36*triangle_tests + 100*shaded + 16*texture_fetches per ray",
+                         "survey_demand_GBps": round(survey_gbps, 1),
+                         "survey_demand_frac": round(survey_gbps / HBM_PEAK_GBPS, 4),
+                         # one glance: the same launch priced three ways against 8 TB/s
+                         "three_fractions": {
+                             "demand_cache_served (survey bytes per ray x walks / launch time; above 1 = not HBM's bytes)": round(survey_gbps / HBM_PEAK_GBPS, 4),
+                             "counter_traffic (FETCH_SIZE x2 + WRITE_SIZE of the committed passes)": round(traffic_gbps / HBM_PEAK_GBPS, 4) if traffic_gbps else None,
+                             "compulsory (frac: pool record in, hit out, walked scene once)": round(achieved / HBM_PEAK_GBPS, 5)},
+                         "l2_hit_rate": kp.get("l2_hit_rate"),
+                         "other_workloads": other_workloads or None,
                          "counter_passes": pmc_source},
             "binding": binding,
             "shared_primary": shared_line,

@@ -63,7 +63,7 @@ def main():
         doc["source_hash"] = bench["source_hash"]
         key = bench["workload_key"]
         w = {"bench_value_mrays_per_s": bench["value"], "seconds_per_frame": bench["seconds_per_frame"]}
-        passes = {n: pass_sums(os.path.join(src, f"pmc_{n}")) for n in ("fetch", "write", "sq", "stall", "stall2")}
+        passes = {n: pass_sums(os.path.join(src, f"pmc_{n}")) for n in ("fetch", "write", "sq", "stall", "stall2", "l2")}
         for short in KERNELS:
             k = {}
             f, nf = passes["fetch"].get(short, ({}, 0))
@@ -97,14 +97,31 @@ def main():
                                          "issuing_lds": round(st.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4)}
                 k["vmem_insts_per_launch"] = round(st.get("SQ_INSTS_VMEM", 0.0) / nst)
                 k["lds_insts_per_launch"] = round(st.get("SQ_INSTS_LDS", 0.0) / nst)
+            l2, nl2 = passes["l2"].get(short, ({}, 0))
+            if nl2 and (l2.get("TCC_HIT_sum", 0.0) + l2.get("TCC_MISS_sum", 0.0)) > 0:
+                # L2 (TCC) look-ups of the kernel's launches, all 8 XCDs: hits / (hits + misses); requests per launch
+                k["l2_hit_rate"] = round(l2.get("TCC_HIT_sum", 0.0) / (l2.get("TCC_HIT_sum", 0.0) + l2.get("TCC_MISS_sum", 0.0)), 4)
+                k["l2_requests_per_launch"] = round(l2.get("TCC_REQ_sum", 0.0) / nl2)
+                k["l2_misses_per_launch"] = round(l2.get("TCC_MISS_sum", 0.0) / nl2)
+                k["l1_to_l2_read_requests_per_launch"] = round(l2.get("TCP_TCC_READ_REQ_sum", 0.0) / nl2)
             s2, ns2 = passes["stall2"].get(short, ({}, 0))
             if ns2:
                 k["stall2_sums"] = {c: v for c, v in s2.items() if c != "GRBM_GUI_ACTIVE"}
             if k:
                 w[short] = k
+        # the dominant kernel's launch priced three ways against 8 TB/s (the bench line of another workload shows these)
+        r = bench.get("roofline", {})
+        kk = w.get(r.get("kernel", ""), {})
+        if kk.get("hbm_bytes_per_launch") and kk.get("kernel_ms_mean"):
+            w["three_fractions"] = {
+                "demand_cache_served": r.get("survey_demand_frac"),
+                "counter_traffic": round(kk["hbm_bytes_per_launch"] / (kk["kernel_ms_mean"] * 1e-3) / 1e9 / 8000.0, 4),
+                "compulsory": r.get("frac"),
+                "hbm_bytes_per_launch": kk["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+                "kernel_ms_mean": kk["kernel_ms_mean"], "l2_hit_rate": kk.get("l2_hit_rate"), "value_mrays_per_s": bench["value"]}
         doc["workloads"][key] = w
         for name in ("bench_default.json", "bench_under_rocprof.json", "bench_kernel_stats.csv", "pmc_fetch.txt", "pmc_write.txt", "pmc_sq.txt",
-                     "pmc_stall.txt", "pmc_stall2.txt"):
+                     "pmc_stall.txt", "pmc_stall2.txt", "pmc_l2.txt"):
             p = os.path.join(src, name)
             if os.path.exists(p):
                 shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
