@@ -148,22 +148,31 @@ __device__ __forceinline__ void ray_set(RayD& r, v3 o, v3 d) {
 // The per-axis early exit there is equivalent to one final t0 > t1 test because t0 never decreases and t1
 // never increases.  The six subtractions and six multiplications run as three packed pairs each -- lane for
 // lane the same IEEE operations as the scalar form.
+// Upstream starts from t0 = -inf, t1 = +inf and folds the axes in with fmaxf / fminf, which drop a NaN operand (0 * inf
+// on an axis the ray runs parallel to, with its origin on the plane).  Here the three axes go into one three-operand
+// maximum and minimum -- the same value unless ALL three operands are NaN, where upstream keeps -inf / +inf and this
+// keeps the NaN.  Everything that reads the results is written so that the two cases cannot be told apart:
+//   t0 is only ever the left side of a "not greater than" test (against t1, against the best t, at once or when it
+//      comes off the stack): false for NaN, false for -inf;
+//   t1 is the right side of the same test against t0 (t0 > +inf and t0 > NaN are both false) and must be positive:
+//      asked as "not (t1 <= 0)", which is true for NaN as t1 > 0 is for +inf, and the same thing for every number.
 __device__ __forceinline__ bool slab(f2v p0, f2v p1, f2v p2, const RayD& r, float& t_near) {
     const f2v d0 = (p0 - r.o_xy) * r.i_xy;      // ax, ay
     const f2v d1 = (p1 - r.o_zx) * r.i_zx;      // az, bx
     const f2v d2 = (p2 - r.o_yz) * r.i_yz;      // by, bz
     const float ax = d0.x, ay = d0.y, az = d1.x, bx = d1.y, by = d2.x, bz = d2.y;
     const bool nx = r.i_xy.x < 0.0f, ny = r.i_xy.y < 0.0f, nz = r.i_zx.x < 0.0f;
-    float t0 = fmaxf(-RT_INF, nx ? bx : ax);
-    float t1 = fminf(RT_INF, nx ? ax : bx);
-    t0 = fmaxf(t0, ny ? by : ay);
-    t1 = fminf(t1, ny ? ay : by);
-    t0 = fmaxf(t0, nz ? bz : az);
-    t1 = fminf(t1, nz ? az : bz);
+    const float t0 = fmaxf(fmaxf(nx ? bx : ax, ny ? by : ay), nz ? bz : az);
+    const float t1 = fminf(fminf(nx ? ax : bx, ny ? ay : by), nz ? az : bz);
     t_near = t0;
-    return !(t0 > t1) & (t1 > 0.0f);
+    return !(t0 > t1) & !(t1 <= 0.0f);
 }
 __device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near) { return slab(a.xy, a.zw, b.xy, r, t_near); }
+
+#ifndef RT_LEAF_NT
+#define RT_LEAF_NT 0
+#endif
+__device__ __forceinline__ float4 as_float4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 struct Hit {
     float t, u, v;
@@ -346,12 +355,19 @@ struct Walker {
         }
         // both records of a two-triangle leaf are fetched at once (one memory round trip per leaf visit, not two); lanes at
         // a one-triangle leaf do not read a second record: every 16-byte piece a lane reads is an L1 access
-        const float4* q = reinterpret_cast<const float4*>(sc.isect + p);
+        const f4v* q = reinterpret_cast<const f4v*>(sc.isect + p);
         const bool pair = (cur & REF_PAIR) != 0;
-        const float4 a0 = q[0], a1 = q[1], a2 = q[2];
+#if RT_LEAF_NT
+        // a triangle record is rarely wanted again soon, a node record is: the hint keeps the L1's lines for the nodes
+        const float4 a0 = as_float4(__builtin_nontemporal_load(q)), a1 = as_float4(__builtin_nontemporal_load(q + 1)), a2 = as_float4(__builtin_nontemporal_load(q + 2));
+        float4 b0, b1, b2;
+        if (pair) { b0 = as_float4(__builtin_nontemporal_load(q + 3)); b1 = as_float4(__builtin_nontemporal_load(q + 4)); b2 = as_float4(__builtin_nontemporal_load(q + 5)); }
+#else
+        const float4 a0 = as_float4(q[0]), a1 = as_float4(q[1]), a2 = as_float4(q[2]);
         // left unset without a second triangle: a default taken from the first record would make the second fetch wait for the first
         float4 b0, b1, b2;
-        if (pair) { b0 = q[3]; b1 = q[4]; b2 = q[5]; }
+        if (pair) { b0 = as_float4(q[3]); b1 = as_float4(q[4]); b2 = as_float4(q[5]); }
+#endif
         tri_test(a0, a1, a2, p, r, h);
         if (pair) tri_test(b0, b1, b2, p + 1, r, h);
         cur = pop(h);
