@@ -15,7 +15,7 @@ HOST     := raytrace_amd/host
 HOSTCXX  ?= g++
 HOSTCXXFLAGS := -std=c++17 -O2 -ffp-contract=off -Wall -Wextra -Iinclude -I$(HOST)
 HOST_OBJS := $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o $(HOST)/scene_loader.o $(HOST)/worker.o $(HOST)/http_server.o
-BINS     := bin/main bin/server bin/obj_dump bin/scene_dump bin/png_tool
+BINS     := bin/main bin/server bin/obj_dump bin/scene_dump bin/png_tool bin/fuzz_readers
 RPATH    := -Wl,-rpath,'$$ORIGIN/../raytrace_amd'
 
 all: $(LIB) oracle host
@@ -44,6 +44,13 @@ bin/png_tool: tools/host/png_tool.cpp $(HOST)/image_io.o $(HOST)/jpeg_decode.o
 bin/scene_dump: tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o $(LIB)
 	@mkdir -p bin
 	$(HOSTCXX) $(HOSTCXXFLAGS) -o $@ tools/host/scene_dump.cpp $(HOST)/scene_loader.o $(HOST)/obj_model.o $(HOST)/image_io.o $(HOST)/jpeg_decode.o -Lraytrace_amd -lrtcore -lz $(RPATH)
+
+# The readers of untrusted text (scene file, OBJ, MTL) once more, with AddressSanitizer and UBSan, under a mutation fuzzer
+# (tests/test_host_fuzz.py runs it; ASAN_OPTIONS=detect_leaks=0 because the HIP runtime librtcore.so pulls in keeps its own).
+bin/fuzz_readers: tools/host/fuzz_readers.cpp $(HOST)/obj_model.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp $(HOST)/jpeg_decode.cpp $(wildcard $(HOST)/*.h) $(LIB)
+	@mkdir -p bin
+	$(HOSTCXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off -Wall -Wextra -Iinclude -I$(HOST) -o $@ \
+	    tools/host/fuzz_readers.cpp $(HOST)/obj_model.cpp $(HOST)/scene_loader.cpp $(HOST)/image_io.cpp $(HOST)/jpeg_decode.cpp -Lraytrace_amd -lrtcore -lz $(RPATH)
 
 $(CSRC)/rt_kernels.o: $(CSRC)/rt_kernels.hip $(CSRC)/rt_build.h $(CSRC)/rt_device.h $(CSRC)/rt_host.h $(CSRC)/rt_packed.h include/rtcore.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

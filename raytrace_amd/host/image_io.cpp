@@ -2,6 +2,8 @@
 // stream over the IDAT chunks, per-row filters 0-4, Adam7 interlacing.
 #include "image_io.h"
 
+#include "file_util.h"
+
 #include <zlib.h>
 
 #include <cctype>
@@ -33,7 +35,7 @@ void put_chunk(std::vector<uint8_t>& file, const char type[4], const uint8_t* da
 
 bool read_file(const std::string& path, std::vector<uint8_t>& bytes) {
     std::ifstream f(path.c_str(), std::ios::binary);
-    if (!f) return false;
+    if (!f || !is_plain_file(path)) return false;
     f.seekg(0, std::ios::end);
     const std::streamoff n = f.tellg();
     if (n < 0) return false;

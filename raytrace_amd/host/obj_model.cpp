@@ -4,6 +4,8 @@
 // loader reads.
 #include "obj_model.h"
 
+#include "file_util.h"
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -335,12 +337,13 @@ bool load_mtl_file(const std::string& name, const std::string& search, std::vect
         std::string dir;
         while (std::getline(dirs, dir, ':')) {
             const std::string path = dir.empty() ? name : (dir.back() == '/' ? dir + name : dir + "/" + name);
+            if (!is_plain_file(path)) continue;
             std::ifstream f(path.c_str());
             if (f) { load_mtl(f, materials, by_name, mtl_warn); warn += mtl_warn; return true; }
         }
     } else {
         std::ifstream f(name.c_str());
-        if (f) { load_mtl(f, materials, by_name, mtl_warn); warn += mtl_warn; return true; }
+        if (is_plain_file(name) && f) { load_mtl(f, materials, by_name, mtl_warn); warn += mtl_warn; return true; }
     }
     warn += "Material file [ " + name + " ] not found in a path : " + search + "\n";
     return false;
@@ -420,7 +423,7 @@ bool parse_decimal(const char* s, const char* s_end, double* out) {
 bool load_obj(const std::string& filename, const std::string& mtl_search_path, ObjModel& model) {
     model = ObjModel();
     std::ifstream in(filename.c_str());
-    if (!in) {
+    if (!in || !is_plain_file(filename)) {
         model.error = "Cannot open file [" + filename + "]\n";
         return false;
     }

@@ -1,6 +1,8 @@
 // scene_loader.cpp -- see scene_loader.h.  Grammar and rules follow csrc/sceneloader.cpp (cited per block).
 #include "scene_loader.h"
 
+#include "file_util.h"
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -277,7 +279,7 @@ int SceneLoader::load_scene(const std::string& filename) {
     parsed_.clear();
     int cur_obj = 0;
     std::ifstream file(filename.c_str());
-    if (!file.is_open()) {
+    if (!file.is_open() || !is_plain_file(filename)) {
         std::cerr << "Error: Cannot open file " << filename << std::endl;
         return -1;
     }
