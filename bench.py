@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--wf-refill", type=int, default=0)
     ap.add_argument("--wf-block", type=int, default=0)
     ap.add_argument("--wf-lanes", type=int, default=0)
+    ap.add_argument("--slot-ring-mb", type=int, default=-1, help="MiB the ring of tile slots may take (default: library default)")
     ap.add_argument("--share-equal", type=int, default=-1, help="1/0: samples that leave a mirror or glass along one ray share its walk / every continued path is walked (default: 0 for the headline, library default beside it)")
     ap.add_argument("--share-primary", type=int, default=-1, help="1/0: one closest-hit walk per pixel and semantic batch / one per sample (default: library default)")
     ap.add_argument("--hot-tune", type=int, default=-1, help="1/0: number the LDS-resident node records by measured visits (default: library default)")
@@ -204,6 +205,8 @@ def main():
         ctx.set_option(capi.OPT_WF_BLOCK, args.wf_block)
     if args.wf_lanes:
         ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
+    if args.slot_ring_mb >= 0:
+        ctx.set_option(capi.OPT_SLOT_RING_MB, args.slot_ring_mb)
     if args.hot_tune >= 0:
         ctx.set_option(capi.OPT_HOT_TUNE, args.hot_tune)
     # the headline counts closest-hit queries as upstream executes them, so it walks every one (see `shared_primary` on the line)

@@ -128,8 +128,9 @@ enum {
     RT_OPT_COUNTERS = 1,      /* 0 = rays/paths only (default), 1 = also box/triangle/shade/texture counts */
     RT_OPT_XCD_REMAP = 2,     /* 1 = give each XCD a contiguous band of pixel tiles (default), 0 = linear */
     RT_OPT_CHUNK = 3,         /* samples one lane traces in a row (default 8); scheduling only, results unchanged */
-    RT_OPT_PASS = 4,          /* samples per pixel buffered between path and accumulate kernels (default 1024, fewer when the
-                                 buffer would pass 64 GiB); scheduling only; the context holds (pass + 1) * n_pixel * 12 bytes */
+    RT_OPT_PASS = 4,          /* samples per pixel traced between two ordered sums (default 1024); scheduling only.  Megakernel: the
+                                 context holds (pass + 1) * n_pixel * 12 bytes of sample slots (fewer samples when that would pass
+                                 64 GiB).  Wavefront: see RT_OPT_SLOT_RING_MB */
     RT_OPT_LDS_SLOTS = 5,     /* traversal-stack levels kept in LDS (default 11); deeper levels spill to private memory */
     RT_OPT_MODE = 6,          /* 0 = megakernel: one kernel traces whole paths; 1 = wavefront (default): path state in HBM,
                                  one kernel per stage with queue compaction.  Same paths, same image, bit for bit.
@@ -164,6 +165,11 @@ enum {
                                  glass (the same way of its two) or a fuzz-free metal reflection leave along one ray again, bit for bit: it
                                  is walked once and every such sample is shaded from that hit.  Same image, RT_CNT_RAYS unchanged,
                                  RT_CNT_WALKS drops.  0 = every continued path is walked */
+    RT_OPT_SLOT_RING_MB = 21, /* wavefront: MiB the sample slots may take (default 10240).  A pass starts its paths tile after tile (16x16
+                                 pixels) and sums a tile's slots as soon as its last path has ended, so the slots are a ring of tiles, each
+                                 pass * 256 * 12 bytes: as many as this allows, never more than the frame has, at least one.  A ring
+                                 shorter than the tiles in flight (about 2400 at the default pool size) holds new paths back; results
+                                 do not depend on it */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (agglomeration in Morton order, rocPRIM sort and scans; 30 M triangles in under 0.1 s),

@@ -52,7 +52,26 @@ struct PathParams {
     int run_len, run_base, n_runs;
     int run_lanes;                        // lanes the shading launch gives a new entry: min(run_len, n_samples)
     uint32_t run_lanes_magic;
+    // Where a path's radiance goes.  ring_tiles == 0: slots[sample of the pass][pixel] (one launch traces the whole
+    // pass, the ordered sum runs after it).  ring_tiles > 0 (wavefront): slots[tile % ring_tiles][sample of the
+    // pass][pixel of the 16x16 tile] -- the pass starts its paths tile after tile, so a tile's slots can be summed and
+    // handed on to a later tile as soon as its last path has ended, and the buffer holds ring_tiles tiles, not the frame.
+    uint32_t ring_tiles, ring_magic, width_magic;
 };
+
+// x / d for a divisor the whole launch shares (see udiv_by below)
+__device__ __forceinline__ uint32_t udiv_by(uint32_t x, uint32_t d, uint32_t m, uint32_t& rem);
+
+// the slot of (pixel, sample) in the layout the pass uses
+__device__ __forceinline__ float* slot_of(const PathParams& pp, uint32_t pixel, int sample) {
+    if (pp.ring_tiles == 0u) return pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+    uint32_t x, place;
+    const uint32_t y = udiv_by(pixel, (uint32_t)pp.cam.width, pp.width_magic, x);
+    const uint32_t tile = (y >> 4) * (uint32_t)pp.tiles_x + (x >> 4);
+    (void)udiv_by(tile, pp.ring_tiles, pp.ring_magic, place);
+    const uint32_t in_tile = ((y & 15u) << 4) | (x & 15u);
+    return pp.slots + (((size_t)place * (size_t)pp.n_samples + (size_t)(sample - pp.first_sample)) * 256u + in_tile) * 3;
+}
 
 // samples [lo, hi) of run k of the pass (see PathParams)
 __device__ __forceinline__ void run_samples(const PathParams& pp, uint32_t k, int& lo, int& hi) {
@@ -399,7 +418,11 @@ __device__ __forceinline__ v3 unit_sphere(uint32_t pixel, uint32_t sample, uint3
         philox(pixel, sample, bounce * 65536u + 1u + attempt, 0u, k0, k1, w0, w1, w2, w3);
         p = mk3(u01(w0) * 2.0f + (-1.0f), u01(w1) * 2.0f + (-1.0f), u01(w2) * 2.0f + (-1.0f));
         attempt++;
+#ifdef RT_EXP_ONE_ATTEMPT
+    } while (false);
+#else
     } while (vdot(p, p) >= 1.0f && attempt < 65535u);
+#endif
     return p;
 }
 

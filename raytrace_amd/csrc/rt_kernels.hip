@@ -125,7 +125,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
             // a path that ran out of depth adds nothing (raytrace.cu:243): its slot holds +0, which is neutral
             // in the ordered sum because every other term is a product of non-negative factors
             if (!contributes) color = mk3(0.0f, 0.0f, 0.0f);
-            float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+            float* slot = slot_of(pp, (uint32_t)pixel, sample);
             slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
             sample++;
             if (sample >= end) alive = false;
@@ -210,6 +210,7 @@ struct WfPools {
 // contiguous run of new path ids.  The closest-hit launch sees the regions' live entries as one sequence
 // (live_prefix) cut into RT_QUEUES queues, one per XCD.
 #define RT_REGIONS_MAX 256u
+#define RT_CURSOR_HISTORY 64u
 struct WfCtl {
     // ---- what the host reads back (RT_CTL_HEAD_BYTES) ----
     uint32_t count_total[2];        // paths in pool 0 / 1 after the last refill of that pool
@@ -227,6 +228,10 @@ struct WfCtl {
     uint32_t gen_prefix[RT_REGIONS_MAX + 1];            // new paths the refill gives to the regions before r
     uint32_t live_prefix[RT_REGIONS_MAX + 1];           // live entries in the regions before r, after the refill
     uint32_t count[2][RT_REGIONS_MAX * RT_QUEUE_STRIDE];   // entries in region r of pool k (one cache line each)
+    // the slot ring (PathParams::ring_tiles): the cursor after each of the last RT_CURSOR_HISTORY refills, the tiles whose
+    // slots have been summed, and the range the ordered sum launched behind this refill is to take
+    unsigned long long cursor_after[RT_CURSOR_HISTORY];
+    uint32_t acc_done, acc_from, acc_to, pad_;
 };
 #define RT_CTL_HEAD_BYTES 80
 static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads back exactly the head of the control block");
@@ -234,8 +239,14 @@ static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads 
 // One workgroup of RT_REGIONS_MAX threads, thread r for region r: sizes the refill of pool `nxt` (free room per region
 // against the paths not yet started), hands out the new path ids region after region, and lays out the closest-hit
 // launch's view of the pool.
+// Slot ring: entries are started tile after tile and an entry started by refill j has ended with the shading launch of
+// iteration j + `lifetime` (every shading launch takes one segment off the depth), so the tiles that lie wholly below the
+// cursor of `lifetime` refills ago are complete: their slots are summed by the launch that follows this one
+// (acc_from..acc_to) and handed on.  New entries are only started for tiles within `ring_tiles` of the last summed one.
+// ring_tiles == 0: no ring, nothing is summed before the pass has drained.
 __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t regions, uint32_t region_cap,
-                                                                 uint32_t per_tile, uint32_t entry_yield, unsigned long long* counters) {
+                                                                 uint32_t per_tile, uint32_t entry_yield, uint32_t ring_tiles, uint32_t lifetime,
+                                                                 unsigned long long* counters) {
     __shared__ uint32_t scan[RT_REGIONS_MAX];
     const uint32_t r = threadIdx.x;
     if (r == 0 && ctl->n_worked) {
@@ -264,7 +275,17 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         __syncthreads();
         return incl - v;
     };
-    const unsigned long long left = total - ctl->cursor;
+    const uint32_t it_now = ctl->iter;
+    uint32_t acc_done = ctl->acc_done, acc_to = acc_done;
+    unsigned long long limit = total;
+    if (ring_tiles) {
+        if (it_now >= lifetime) acc_to = (uint32_t)(ctl->cursor_after[(it_now - lifetime) % RT_CURSOR_HISTORY] / per_tile);
+        if (acc_to < acc_done) acc_to = acc_done;
+        limit = ((unsigned long long)acc_to + ring_tiles) * per_tile;
+        if (limit > total) limit = total;
+    }
+    const unsigned long long cursor_now = ctl->cursor;
+    const unsigned long long left = limit > cursor_now ? limit - cursor_now : 0ull;
     const uint32_t before = exclusive(room);
     const uint32_t given = (unsigned long long)before >= left ? 0u : (uint32_t)(left - before < (unsigned long long)room ? left - before : room);
     const uint32_t new_before = exclusive(given);
@@ -292,9 +313,56 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         ctl->gen_rem = (uint32_t)(ctl->cursor % per_tile);
         ctl->gen_tile = (uint32_t)(ctl->cursor / per_tile);
         ctl->cursor += n;
+        ctl->cursor_after[it % RT_CURSOR_HISTORY] = ctl->cursor;
+        ctl->acc_from = acc_done; ctl->acc_to = acc_to; ctl->acc_done = acc_to;
         ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
     }
     if (r < RT_QUEUES) ctl->queue_next[r * RT_QUEUE_STRIDE] = 0;
+}
+
+// The same ordered sum for the tile layout of the wavefront variant (PathParams::ring_tiles): a workgroup takes a tile, a
+// thread a pixel of it.  The tiles to sum come from the control block -- [acc_from, acc_to) as the refill planner set them,
+// or with `rest` whatever is left up to `n_tiles` once the pass has drained.  Every pixel is summed once per pass, over
+// all samples of the pass in order, so the additions and their order are those of accumulate_kernel.
+__global__ __launch_bounds__(RT_BLOCK) void accumulate_tiles_kernel(const WfCtl* __restrict__ ctl, int rest, uint32_t n_tiles, uint32_t ring_tiles, int tiles_x,
+                                                                    int width, int height, int first_sample, int n_samples, int batch, int flush,
+                                                                    const float* __restrict__ slots, float* __restrict__ carry, float* __restrict__ out) {
+    const uint32_t from = rest ? ctl->acc_done : ctl->acc_from, to = rest ? n_tiles : ctl->acc_to;
+    for (uint32_t tile = from + blockIdx.x; tile < to; tile += gridDim.x) {
+        const int tx = (int)(tile % (uint32_t)tiles_x), ty = (int)(tile / (uint32_t)tiles_x);
+        const int x = tx * 16 + (int)(threadIdx.x & 15u), y = ty * 16 + (int)(threadIdx.x >> 4);
+        if (x >= width || y >= height) continue;
+        const size_t i = (size_t)y * (size_t)width + (size_t)x;
+        const float* p = slots + ((size_t)(tile % ring_tiles) * (size_t)n_samples * 256u + threadIdx.x) * 3;
+        float ox = out[3 * i], oy = out[3 * i + 1], oz = out[3 * i + 2];
+        float tx_ = 0.0f, ty_ = 0.0f, tz_ = 0.0f;
+        int in_batch = first_sample % batch;
+        if (in_batch) { tx_ = carry[3 * i]; ty_ = carry[3 * i + 1]; tz_ = carry[3 * i + 2]; }
+        // sixteen samples' loads are in flight before the first of them is added: a launch has few tiles (the ones
+        // completed since the last refill), so the memory parallelism has to come from inside the thread
+        for (int s = 0; s < n_samples; s += 16, p += 16 * 256 * 3) {
+            float v[16][3];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (s + k < n_samples) { v[k][0] = p[k * 768]; v[k][1] = p[k * 768 + 1]; v[k][2] = p[k * 768 + 2]; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (s + k < n_samples) {
+                    tx_ += v[k][0]; ty_ += v[k][1]; tz_ += v[k][2];
+                    if (++in_batch == batch) {
+                        ox += tx_; oy += ty_; oz += tz_;
+                        tx_ = ty_ = tz_ = 0.0f;
+                        in_batch = 0;
+                    }
+                }
+            }
+        }
+        if (in_batch) {
+            if (flush) { ox += tx_; oy += ty_; oz += tz_; }
+            else { carry[3 * i] = tx_; carry[3 * i + 1] = ty_; carry[3 * i + 2] = tz_; }
+        }
+        out[3 * i] = ox; out[3 * i + 1] = oy; out[3 * i + 2] = oz;
+    }
 }
 
 // The shading kernel streams the pools: it reads every record once and writes every survivor once, and a pool is far
@@ -388,7 +456,7 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
                 if (depth == 0) {
                     // `while (depth--)` never runs: the paths add nothing (raytrace.cu:213, 243)
                     for (int smp = s_lo; smp < s_hi; smp++) {
-                        float* slot = pp.slots + ((size_t)(smp - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                        float* slot = slot_of(pp, (uint32_t)pixel, smp);
                         slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
                     }
                     depth = -1;
@@ -703,7 +771,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
                 }
                 if (finished) {
                     n_paths = 1;
-                    float* slot = pp.slots + ((size_t)(sample - pp.first_sample) * (size_t)pp.n_pixel + (size_t)pixel) * 3;
+                    float* slot = slot_of(pp, (uint32_t)pixel, sample);
                     slot[0] = color.x; slot[1] = color.y; slot[2] = color.z;
                 } else {
                     survives = true;
@@ -920,8 +988,9 @@ struct rt_context {
     int opt_wf_lanes = 1;            // pipelines per pass (2 measured slower: the second pipeline's shading starves behind the first's closest-hit launch)
     uint32_t pool_capacity = 0;
     uint32_t pool_cap_limit = 0xFFFFFFFFu;   // the largest pool this device had memory for, once an allocation has failed
-    float* d_slots = nullptr;        // [pass][n_pixel][3], then one [n_pixel][3] carry plane
+    float* d_slots = nullptr;        // the sample slots of a pass (layouts: PathParams::ring_tiles), then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
+    size_t slots_ring_bytes = (size_t)10 << 30;   // wavefront: what the ring of tile slots may take (less for a small frame: never more than the frame's tiles)
     int stack_slots = 1;
     uint64_t stats[8] = {0};
 };
@@ -1082,6 +1151,9 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_PASS:
         if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "rt_set_option: pass must be 1..65536");
         ctx->opt_pass = value; return RT_OK;
+    case RT_OPT_SLOT_RING_MB:
+        if (value < 0 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: slot ring must be 0..2^20 MiB");
+        ctx->slots_ring_bytes = (size_t)value << 20; return RT_OK;
     default: return fail(RT_ERR_INVALID, "rt_set_option: unknown option");
     }
 }
@@ -1258,8 +1330,15 @@ static void set_runs(PathParams& pp, int run_len) {
 
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
 // samples are split between the pipelines; every path writes its own slot, so the split changes no result.
-static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
+// The ordered sum of the pass's slots into `d_output` is part of the pass: with one pipeline it follows the paths tile by
+// tile through the slot ring (`ring_tiles` tiles of slots at pp.slots), with two it runs when both have drained.
+static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_t ring_tiles, float* carry, float* d_output, int flush) {
     const int n_lanes = (ctx->opt_wf_lanes > 1 && pp.n_samples > 1) ? 2 : 1;
+    const uint32_t n_tiles = (uint32_t)pp.tiles_x * (uint32_t)pp.tiles_y;
+    // the sum can only follow the paths while the planner remembers the cursor of `lifetime` refills ago
+    const uint32_t lifetime = (uint32_t)std::max(1, pp.max_depth);
+    const bool follow = n_lanes == 1 && lifetime < RT_CURSOR_HISTORY;
+    if (!follow && ring_tiles < n_tiles) return fail(RT_ERR_INVALID, "rt_raytrace: internal: a slot ring shorter than the frame needs the following sum");
     // pool size: the option's, but no larger than the pass needs (a small frame should not launch grids sized for a
     // large one, nor hold gigabytes of pools); the pools only ever grow
     const unsigned long long pass_paths = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)pp.n_samples;
@@ -1335,7 +1414,11 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         R.pp = pp;
         R.pp.first_sample = pp.first_sample + first;
         R.pp.n_samples = last - first;
-        R.pp.slots = pp.slots + (size_t)first * (size_t)pp.n_pixel * 3;
+        // tile layout: [tile][sample of the pipeline's share][256]; the second pipeline's slots follow the first's
+        R.pp.slots = pp.slots + (size_t)first * (size_t)ring_tiles * 256u * 3;
+        R.pp.ring_tiles = ring_tiles;
+        R.pp.ring_magic = magic_of(ring_tiles);
+        R.pp.width_magic = magic_of((uint32_t)pp.cam.width);
         // one closest-hit query per pixel and semantic batch, unless the option says one per sample or a run's survivors
         // would take more than an eighth of a region
         const uint32_t longest_run = (uint32_t)std::min(pp.batch, R.pp.n_samples);
@@ -1346,7 +1429,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         // A pass whose entries all fit the first refill needs no look at the pool's population: iteration i traces segment
         // i of every path, so the shading of iteration max_depth ends the last of them.  (An interactive frame of a few
         // samples otherwise pays up to eight empty iterations before the snapshots tell.)
-        R.stop_known = R.total <= (unsigned long long)regions * ((cap / regions) / R.entry_yield);
+        R.stop_known = R.total <= (unsigned long long)regions * ((cap / regions) / R.entry_yield) && ring_tiles >= n_tiles;
         R.stop_at = (unsigned)std::max(1, pp.max_depth);
         // (Longer passes learn the iteration of the last start from the snapshots, a group late but well before it matters.)
         R.cur = 0;
@@ -1358,6 +1441,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
     }
     const dim3 grid(std::min<uint32_t>(cap / RT_BLOCK, (uint32_t)ctx->n_cu * 64u)), block(RT_BLOCK);
     const dim3 sgrid(cap / RT_SHADE_BLOCK), sblock(RT_SHADE_BLOCK);
+    const dim3 agrid(std::min<uint32_t>(n_tiles, (uint32_t)ctx->n_cu * 16u));
     // one launch fills the chip once; the waves share out the pool themselves
     const uint32_t wanted = (cap + rpb * (eb / 64) - 1) / (rpb * (eb / 64));
     const dim3 egrid(std::min<uint32_t>(wanted, (uint32_t)ctx->n_cu * (2048u / eb))), eblock(eb);
@@ -1382,7 +1466,13 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
                 }
             }
             hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, R.pp.per_tile, R.entry_yield,
-                               ctx->d_counters);
+                               follow ? ring_tiles : 0u, lifetime, ctx->d_counters);
+            // the tiles whose last path has ended are summed now, before any later tile's paths write to their places in the ring
+            // (On a stream of its own beside the closest-hit launch the sum cost more than it hid: it pushes 30 GB per pass
+            // through the L2 the walk lives in -- closest-hit launches +4 %.)
+            if (follow && R.iter >= lifetime)
+                hipLaunchKernelGGL(accumulate_tiles_kernel, agrid, dim3(RT_BLOCK), 0, ls, (const WfCtl*)L.d_ctl, 0, n_tiles, ring_tiles, R.pp.tiles_x, R.pp.cam.width,
+                                   R.pp.cam.height, R.pp.first_sample, R.pp.n_samples, R.pp.batch, flush, (const float*)R.pp.slots, carry, d_output);
             hipLaunchKernelGGL(wf_generate_kernel, grid, block, 0, ls, (const WfCtl*)L.d_ctl, L.pools, nxt, regions, log2_region_cap, R.pp);
             const int tke = timing_begin(ctx, 0, ls);
             {
@@ -1421,6 +1511,14 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s) {
         HIP_TRY(hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].stream));
         HIP_TRY(hipStreamWaitEvent(s, ctx->lanes[l].done, 0));
     }
+    // what the following sum has not taken (everything, without it), on the caller's stream: the pipelines' shares in sample
+    // order, a batch that straddles two shares carried from one to the next like a batch that straddles two passes
+    for (int l = 0; l < n_lanes; l++) {
+        const LaneRun& R = run[l];
+        hipLaunchKernelGGL(accumulate_tiles_kernel, agrid, dim3(RT_BLOCK), 0, s, (const WfCtl*)ctx->lanes[l].d_ctl, 1, n_tiles, ring_tiles, R.pp.tiles_x, R.pp.cam.width,
+                           R.pp.cam.height, R.pp.first_sample, R.pp.n_samples, R.pp.batch, (flush && l == n_lanes - 1) ? 1 : 0, (const float*)R.pp.slots, carry, d_output);
+    }
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 
@@ -1495,34 +1593,68 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     if (n_pixel > (int)RT_PIXEL_MASK) return fail(RT_ERR_INVALID, name + ": more than 2^26-1 pixels");
     if (!stack_fits(ctx)) return fail(RT_ERR_INVALID, name + ": BVH deeper than the traversal stack allows");
     HIP_TRY(hipSetDevice(ctx->device));
-    // slot buffer: one float3 per (sample of the pass, pixel), then one carry plane
-    // Long passes pay the pipeline's drain (a dozen launches with a thinning pool) less often; the context's buffer is sized
-    // for a 288 GB device but kept below RT_SLOTS_MAX_BYTES.
+    // Slot buffer.  Megakernel: one float3 per (sample of the pass, pixel), then one carry plane; the pass is as long as
+    // the buffer allows.  Wavefront: a ring of 16x16-pixel tiles, each with a float3 per (sample of the pass, pixel of
+    // the tile), then the carry plane: the pass starts its paths tile after tile and sums a tile's slots as soon as its
+    // last path has ended, so the ring only has to hold the tiles that have paths in flight -- about
+    // RT_SLOTS_RING_BYTES whatever the frame, and a pass can be as long as RT_OPT_PASS says.
+    const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
     const size_t plane = (size_t)n_pixel * 3 * sizeof(float);
     int pass = spp < ctx->opt_pass ? spp : ctx->opt_pass;
-    const size_t fit = (fixed_slots ? fixed_bytes : RT_SLOTS_MAX_BYTES) / plane;
-    if (fixed_slots && fit < 2)
-        return fail(RT_ERR_CAPACITY, name + ": a frame of " + std::to_string(n_pixel) + " pixels needs " + std::to_string(2 * plane) +
-                                     " bytes of sample slots, the static array holds " + std::to_string(fixed_bytes));
-    if (fit >= 2 && (size_t)pass > fit - 1) pass = (int)(fit - 1);
+    const uint32_t n_tiles = (uint32_t)((ctx->cam.width + 15) / 16) * (uint32_t)((ctx->cam.height + 15) / 16);
+    uint32_t ring_tiles = 0;
     float* slots = fixed_slots;
-    if (!fixed_slots) {
-        size_t need = ((size_t)pass + 1) * plane;
+    float* carry = nullptr;
+    if (wavefront) {
+        const bool one_pipeline = !(ctx->opt_wf_lanes > 1 && pass > 1) && std::max(1, max_depth) < (int)RT_CURSOR_HISTORY;
+        auto ring_for = [&](int pass_len) {
+            const size_t tile_bytes = (size_t)pass_len * 256u * 3 * sizeof(float);
+            const size_t want = one_pipeline ? std::max<size_t>(1, ctx->slots_ring_bytes / tile_bytes) : (size_t)n_tiles;
+            return (uint32_t)std::min<size_t>(n_tiles, want);
+        };
+        ring_tiles = ring_for(pass);
+        size_t need = (size_t)ring_tiles * (size_t)pass * 256u * 3 * sizeof(float) + plane;
         if (need > ctx->slots_bytes) {
             HIP_TRY(hipStreamSynchronize(s));
             if (ctx->d_slots) { HIP_TRY(hipFree(ctx->d_slots)); ctx->d_slots = nullptr; ctx->slots_bytes = 0; }
-            // a device with less free memory than the defaults assume gets shorter passes, not an error
+            // a device with less free memory than the defaults assume gets a shorter ring (or shorter passes), not an error
             hipError_t e = hipMalloc((void**)&ctx->d_slots, need);
-            while (e == hipErrorOutOfMemory && pass > 1) {
+            while (e == hipErrorOutOfMemory && (ring_tiles > 1 || pass > 1)) {
                 (void)hipGetLastError();
-                pass = (pass + 1) / 2;
-                need = ((size_t)pass + 1) * plane;
+                if (one_pipeline && ring_tiles > 64) ring_tiles = (ring_tiles + 1) / 2;
+                else { pass = (pass + 1) / 2; ring_tiles = std::min(ring_tiles, ring_for(pass)); }
+                need = (size_t)ring_tiles * (size_t)pass * 256u * 3 * sizeof(float) + plane;
                 e = hipMalloc((void**)&ctx->d_slots, need);
             }
             if (e != hipSuccess) { ctx->d_slots = nullptr; return fail(RT_ERR_DEVICE, name + ": hipMalloc of the sample slots: " + hipGetErrorString(e)); }
             ctx->slots_bytes = need;
         }
         slots = ctx->d_slots;
+        carry = slots + (size_t)ring_tiles * (size_t)pass * 256u * 3;
+    } else {
+        const size_t fit = (fixed_slots ? fixed_bytes : RT_SLOTS_MAX_BYTES) / plane;
+        if (fixed_slots && fit < 2)
+            return fail(RT_ERR_CAPACITY, name + ": a frame of " + std::to_string(n_pixel) + " pixels needs " + std::to_string(2 * plane) +
+                                         " bytes of sample slots, the static array holds " + std::to_string(fixed_bytes));
+        if (fit >= 2 && (size_t)pass > fit - 1) pass = (int)(fit - 1);
+        if (!fixed_slots) {
+            size_t need = ((size_t)pass + 1) * plane;
+            if (need > ctx->slots_bytes) {
+                HIP_TRY(hipStreamSynchronize(s));
+                if (ctx->d_slots) { HIP_TRY(hipFree(ctx->d_slots)); ctx->d_slots = nullptr; ctx->slots_bytes = 0; }
+                hipError_t e = hipMalloc((void**)&ctx->d_slots, need);
+                while (e == hipErrorOutOfMemory && pass > 1) {
+                    (void)hipGetLastError();
+                    pass = (pass + 1) / 2;
+                    need = ((size_t)pass + 1) * plane;
+                    e = hipMalloc((void**)&ctx->d_slots, need);
+                }
+                if (e != hipSuccess) { ctx->d_slots = nullptr; return fail(RT_ERR_DEVICE, name + ": hipMalloc of the sample slots: " + hipGetErrorString(e)); }
+                ctx->slots_bytes = need;
+            }
+            slots = ctx->d_slots;
+        }
+        carry = slots + (size_t)pass * (size_t)n_pixel * 3;
     }
     PathParams pp;
     pp.cam = ctx->cam;
@@ -1543,7 +1675,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.hist = nullptr;
     pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
     pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_lanes = 1; pp.run_lanes_magic = 0xFFFFFFFFu;
-    const bool wavefront = !fixed_slots && ctx->opt_mode == 1;
+    pp.ring_tiles = 0; pp.ring_magic = 0; pp.width_magic = 0;                   // the linear slot layout, unless the wavefront pass says otherwise
     if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
         pp.first_sample = first_sample;
         const int rc = tune_hot_nodes(ctx, pp, s);
@@ -1555,9 +1687,11 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
         pp.n_chunks = (pp.n_samples + pp.chunk - 1) / pp.chunk;
         const long long nblocks = (long long)pp.tiles_x * pp.tiles_y * pp.n_chunks;
         if (nblocks > 0x7FFFFFFFLL) return fail(RT_ERR_INVALID, name + ": grid too large");
+        const int last = done + pass >= spp ? 1 : 0;
         if (wavefront) {
-            const int rc = wavefront_pass(ctx, pp, s);
+            const int rc = wavefront_pass(ctx, pp, s, ring_tiles, carry, d_output, last);
             if (rc) return rc;
+            continue;                                   // the pass summed its own slots
         } else {
             const int tk = fixed_slots ? -1 : timing_begin(ctx, 2, s);     // timing creates events on demand
             if (ctx->opt_counters) hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
@@ -1566,8 +1700,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixel + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, n_pixel, pp.first_sample,
-                           pp.n_samples, semantic_batch, done + pass >= spp ? 1 : 0, (const float*)slots,
-                           slots + (size_t)pass * (size_t)n_pixel * 3, d_output);
+                           pp.n_samples, semantic_batch, last, (const float*)slots, carry, d_output);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;

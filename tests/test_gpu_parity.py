@@ -596,6 +596,44 @@ def test_library_defaults_all_at_once_against_the_oracle():
     assert ccnt[capi.CNT_HOT_VISITS] > 0
 
 
+@pytest.mark.parametrize("name,kw,spp,batch,ring_mb,cap,shared", [
+    ("material_box", dict(width=200, height=120, n_samples=32), 32, 8, 1, 14, 0),       # 104 tiles, a ring of 10: the planner holds new paths back
+    ("material_box", dict(width=200, height=120, n_samples=32), 32, 8, 1, 14, 1),       # the same with the first walk shared
+    ("material_box", dict(width=200, height=120, n_samples=20), 20, 8, 0, 18, 1),       # a ring of ONE tile; the pass ends inside a batch
+    ("room", dict(width=120, height=80, n_samples=16, detail=0.2, tex_size=64), 16, 4, 1, 14, 1),   # depth 16: paths live twice as long
+    ("formula1", dict(width=400, height=240, n_samples=32, detail=0.1, tex_size=64), 32, 16, 2, 16, 1),
+])
+def test_slot_ring_shorter_than_the_frame_bit_exact(gpu_ctx, name, kw, spp, batch, ring_mb, cap, shared):
+    """The wavefront pass sums a 16x16 tile's slots as soon as the tile's last path has ended and hands the tile's place in
+    the slot ring to a later tile (RT_OPT_SLOT_RING_MB).  With a ring far shorter than the frame the planner has to hold
+    new paths back until places come free: the image and the counts must be those of the oracle all the same, in one call
+    and in two calls that split the samples."""
+    p = Pair(gpu_ctx, getattr(scene, name)(**kw))
+    ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, batch), 0, spp)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, cap)
+    gpu_ctx.set_option(capi.OPT_SLOT_RING_MB, ring_mb)
+    gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, shared)
+    gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, shared)
+    try:
+        got, gcnt = p.gpu_render(0, spp, batch)
+        half = (spp // 2) // batch * batch
+        part, _ = p.gpu_render(0, half, batch)
+        part, _ = p.gpu_render(half, spp - half, batch, accum=part)
+        gpu_ctx.set_option(capi.OPT_PASS, 8)                         # several passes per call, each with its own ring
+        passes, _ = p.gpu_render(0, spp, batch)
+    finally:
+        gpu_ctx.set_option(capi.OPT_PASS, 1024)
+        gpu_ctx.set_option(capi.OPT_SLOT_RING_MB, 10240)
+        gpu_ctx.set_option(capi.OPT_SHARE_PRIMARY, 0)
+        gpu_ctx.set_option(capi.OPT_SHARE_EQUAL, 0)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
+    assert same_f32(got, ref), f"{(bits(got) != bits(ref)).any(axis=1).sum()} of {len(ref)} pixels differ"
+    assert same_f32(part, ref) and same_f32(passes, ref)
+    assert gcnt[capi.CNT_RAYS] == rcnt[0] and gcnt[capi.CNT_SHADED] == rcnt[3] and gcnt[capi.CNT_PATHS] == p.cfg.width * p.cfg.height * spp
+
+
 def _runs(first, n, batch):
     """Semantic batches the samples [first, first + n) touch: one shared walk each."""
     return (first + n - 1) // batch - first // batch + 1 if n > 0 else 0
