@@ -211,6 +211,7 @@ struct WfPools {
 // (live_prefix) cut into RT_QUEUES queues, one per XCD.
 #define RT_REGIONS_MAX 256u
 #define RT_CURSOR_HISTORY 64u
+#define RT_SUM_LOT_TILES 1024u      // completed tiles the ordered sum waits for before it runs (unless the slot ring is full)
 struct WfCtl {
     // ---- what the host reads back (RT_CTL_HEAD_BYTES) ----
     uint32_t count_total[2];        // paths in pool 0 / 1 after the last refill of that pool
@@ -276,17 +277,29 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         return incl - v;
     };
     const uint32_t it_now = ctl->iter;
-    uint32_t acc_done = ctl->acc_done, acc_to = acc_done;
+    const unsigned long long cursor_now = ctl->cursor;
+    const uint32_t acc_done = ctl->acc_done;
+    const uint32_t before = exclusive(room);
+    // the room of all regions together: what this refill would start if nothing held it back
+    __shared__ uint32_t all_room;
+    if (r == RT_REGIONS_MAX - 1u) all_room = before + room;
+    __syncthreads();
+    uint32_t acc_to = acc_done;
     unsigned long long limit = total;
     if (ring_tiles) {
-        if (it_now >= lifetime) acc_to = (uint32_t)(ctl->cursor_after[(it_now - lifetime) % RT_CURSOR_HISTORY] / per_tile);
-        if (acc_to < acc_done) acc_to = acc_done;
+        uint32_t complete = acc_done;
+        if (it_now >= lifetime) complete = (uint32_t)(ctl->cursor_after[(it_now - lifetime) % RT_CURSOR_HISTORY] / per_tile);
+        if (complete < acc_done) complete = acc_done;
+        // Completed tiles are summed in large lots (a launch over a few dozen tiles cannot keep HBM busy), unless the
+        // ring is so full that waiting would hold this refill back.
+        const unsigned long long wanted = cursor_now + (unsigned long long)all_room < total ? cursor_now + all_room : total;
+        const bool ring_full = ((unsigned long long)acc_done + ring_tiles) * per_tile < wanted;
+        const bool all_complete = (unsigned long long)complete * per_tile >= total;
+        if (complete - acc_done >= RT_SUM_LOT_TILES || ring_full || all_complete) acc_to = complete;
         limit = ((unsigned long long)acc_to + ring_tiles) * per_tile;
         if (limit > total) limit = total;
     }
-    const unsigned long long cursor_now = ctl->cursor;
     const unsigned long long left = limit > cursor_now ? limit - cursor_now : 0ull;
-    const uint32_t before = exclusive(room);
     const uint32_t given = (unsigned long long)before >= left ? 0u : (uint32_t)(left - before < (unsigned long long)room ? left - before : room);
     const uint32_t new_before = exclusive(given);
     const uint32_t live_before = exclusive(have + given);
