@@ -10,6 +10,7 @@ one="--share-primary 0"
 case " $* " in *" --share-primary "*) one="";; esac
 export TMPDIR=/tmp
 out=gpurun_out/$tag
+rm -rf $out      # counter files of an earlier run under the same tag would be summed in
 mkdir -p $out
 timeout -k 10 400 python3 bench.py "$@" > $out/bench_default.json 2> $out/bench_default.log
 mkdir -p $out/trace
