@@ -430,8 +430,19 @@ def main():
                      "vector L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES / CUs / cycles; ceiling 1)": kp.get("l1_accesses_per_clk_per_cu"),
                      "HBM traffic / 8 TB/s (FETCH_SIZE x 2 + WRITE_SIZE)": round(traffic_gbps / HBM_PEAK_GBPS, 4) if traffic_gbps else None}
             roofs = {k: v for k, v in roofs.items() if v is not None}
-            top = max(roofs, key=roofs.get)
-            binding = {"roof": top, "frac": roofs[top], "all": roofs, "wave_cycle_split": kp.get("wave_cycle_split"),
+            busiest = max(roofs, key=roofs.get)
+            l1_key = "vector L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES / CUs / cycles; ceiling 1)"
+            # The busiest unit is not by itself the one the kernel waits for.  For the closest-hit kernel two measurements decide
+            # (profiles/experiments/r03_extend.md): 8-10 vector instructions fewer per node visit moved it by 0.3 %, and the L1
+            # serves one lane access per clock per CU however few lanes a load has active -- the latency-bound waves of four
+            # SIMDs queue for that port.
+            top = l1_key if (kname == "wf_extend_kernel" and l1_key in roofs) else busiest
+            binding = {"roof": top, "frac": roofs[top], "busiest_unit": busiest, "all": roofs,
+                       "why": ("vector issue is the busier unit, but removing 8-10 of ~85 vector instructions per node visit changed the kernel's time by "
+                               "0.3 %; the vector L1 charges every ACTIVE lane one clock (microbenchmark tools/microbench/l1_lanes.hip: 19/34/49/64 "
+                               "clocks per wave-level load with 16/32/48/64 lanes), hits included, and is what the waves queue for")
+                               if top != busiest else None,
+                       "wave_cycle_split": kp.get("wave_cycle_split"),
                        "resident_waves_mean": kp.get("mean_waves_in_flight"), "resident_wave_limit": kp.get("resident_wave_limit")}
         what = "closest-hit queries as upstream counts them; coinciding rays are walked once" if args.share_primary == 1 else "closest-hit queries"
         out = {
