@@ -57,6 +57,12 @@ struct PathParams {
     // pass][pixel of the 16x16 tile] -- the pass starts its paths tile after tile, so a tile's slots can be summed and
     // handed on to a later tile as soon as its last path has ended, and the buffer holds ring_tiles tiles, not the frame.
     uint32_t ring_tiles, ring_magic, width_magic;
+    // Order of a tile's entries when every sample has an entry of its own (run_len == 1).  group_log2 == 0: run after run,
+    // each a tile's 256 pixels.  Otherwise runs come in groups of G = 2^group_log2 and a group is laid out pixel after
+    // pixel, each pixel's G samples side by side: the samples of a semantic batch start with one and the same primary ray
+    // (cuda/raytrace.cu:210), and rays that coincide, held by neighbouring lanes, ask the L1 for one address where
+    // scattered lanes ask for G.  n_full_groups whole groups, then one of group_rem runs.
+    uint32_t group_log2, n_full_groups, group_rem, group_rem_magic;
 };
 
 // x / d for a divisor the whole launch shares (see udiv_by below)
@@ -90,6 +96,22 @@ __device__ __forceinline__ uint32_t udiv_by(uint32_t x, uint32_t d, uint32_t m, 
     if (r >= d) { q++; r -= d; }
     rem = r;
     return q;
+}
+
+// place of (run k, pixel p of the tile) among the tile's entries, and the run of a place (see PathParams::group_log2)
+__device__ __forceinline__ uint32_t place_of(const PathParams& pp, uint32_t k, uint32_t p) {
+    if (pp.group_log2 == 0u) return k * 256u + p;
+    const uint32_t g = k >> pp.group_log2, span = 8u + pp.group_log2;
+    if (g < pp.n_full_groups) return (g << span) + (p << pp.group_log2) + (k & ((1u << pp.group_log2) - 1u));
+    return (pp.n_full_groups << span) + p * pp.group_rem + (k - (pp.n_full_groups << pp.group_log2));
+}
+__device__ __forceinline__ uint32_t run_of_place(const PathParams& pp, uint32_t w) {
+    if (pp.group_log2 == 0u) return w >> 8;
+    const uint32_t span = 8u + pp.group_log2, g = w >> span;
+    if (g < pp.n_full_groups) return (g << pp.group_log2) + (w & ((1u << pp.group_log2) - 1u));
+    uint32_t j;
+    (void)udiv_by(w - (pp.n_full_groups << span), pp.group_rem, pp.group_rem_magic, j);
+    return (pp.n_full_groups << pp.group_log2) + j;
 }
 
 #define RT_BLOCK 256

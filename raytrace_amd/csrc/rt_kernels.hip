@@ -436,8 +436,68 @@ __global__ __launch_bounds__(RT_BLOCK) void wf_generate_kernel(const WfCtl* __re
         uint32_t batch_of_dir = 0xFFFFFFFFu;
         v3 dir = mk3(0.0f, 0.0f, 1.0f);
         const uint32_t k_end = min((uint32_t)pp.n_runs, (chunk + 1u) * RT_GEN_RUN);
+        if (pp.group_log2) {
+            // One entry per sample, a group's samples side by side (PathParams::group_log2): the 64 pixels of this wave
+            // times the group's runs are one contiguous stretch of places.  The group lies inside one semantic batch, so
+            // its entries of one pixel are one and the same record: every lane works out its own pixel's record once per
+            // group, and the wave writes the stretch 64 consecutive places at a time, each lane fetching the record of the
+            // pixel its place belongs to from the lane that made it.
+            const uint32_t G = 1u << pp.group_log2, p0 = p & ~63u;
+            for (uint32_t k0 = chunk * RT_GEN_RUN; k0 < k_end; k0 += G) {
+                const uint32_t glen = min(G, k_end - k0), glen_magic = glen == G ? 0u : pp.group_rem_magic;
+                int depth = pp.max_depth;
+                if (inside) {
+                    int s_lo, s_hi;
+                    run_samples(pp, k0, s_lo, s_hi);
+                    uint32_t in_batch;
+                    const uint32_t batch_index = udiv_by((uint32_t)s_lo, (uint32_t)pp.batch, pp.batch_magic, in_batch);
+                    if (batch_index != batch_of_dir) {
+                        uint32_t w0, w1, w2, w3;
+                        philox((uint32_t)pixel, batch_index, 0u, 1u, pp.key0, pp.key1, w0, w1, w2, w3);
+                        dir = primary_dir(pp.cam, x, y, u01(w0), u01(w1));
+                        batch_of_dir = batch_index;
+                    }
+                    if (depth == 0) {
+                        for (int smp = s_lo; smp < s_lo + (int)glen; smp++) {
+                            float* slot = slot_of(pp, (uint32_t)pixel, smp);
+                            slot[0] = 0.0f; slot[1] = 0.0f; slot[2] = 0.0f;
+                        }
+                        depth = -1;
+                        n_paths += glen;
+                    }
+                } else {
+                    depth = -1;
+                }
+                const uint32_t word = depth > 0 ? ((uint32_t)pixel | RT_FRESH_PATH) : 0xFFFFFFFFu;
+                const uint32_t stretch = tile_rel * pp.per_tile + place_of(pp, k0, p0);
+                for (uint32_t i = 0; i < glen; i++) {                  // the same trip count in every lane: the exchanges below need the whole wave
+                    const uint32_t e = i * 64u + (uint32_t)lane;
+                    uint32_t within;
+                    const uint32_t owner = glen == G ? e >> pp.group_log2 : udiv_by(e, glen, glen_magic, within);
+                    const float ex = __shfl(dir.x, (int)owner, 64), ey = __shfl(dir.y, (int)owner, 64), ez = __shfl(dir.z, (int)owner, 64);
+                    const uint32_t ew = (uint32_t)__shfl((int)word, (int)owner, 64);
+                    const uint32_t along = stretch + e;
+                    if (along < gen_rem) continue;
+                    const uint32_t j = along - gen_rem;
+                    if (j >= gen_count) continue;
+                    if (reg == RT_REGIONS_MAX) {
+                        uint32_t lo = 0, hi = regions - 1;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi + 1) >> 1;
+                            if (new_before[mid] <= j) lo = mid; else hi = mid - 1;
+                        }
+                        reg = lo;
+                    } else {
+                        while (reg + 1 < regions && new_before[reg + 1] <= j) reg++;
+                    }
+                    const uint32_t pos = (reg << log2_region_cap) + ctl->gen_base[reg] + (j - new_before[reg]);
+                    pools.p0[nxt][pos] = make_float4(ex, ey, ez, __uint_as_float(ew));
+                }
+            }
+            continue;
+        }
         for (uint32_t k = chunk * RT_GEN_RUN; k < k_end; k++) {
-            const uint32_t along = tile_rel * pp.per_tile + k * 256u + p;
+            const uint32_t along = tile_rel * pp.per_tile + place_of(pp, k, p);
             if (along < gen_rem) continue;                   // before the refill's first id (its first tile only)
             const uint32_t j = along - gen_rem;
             if (j >= gen_count) break;                       // past its last id (its last tile only)
@@ -755,7 +815,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void wf_shade_kernel(SceneDev sc, W
                 uint32_t in_tile;
                 (void)udiv_by(ctl->gen_rem + ctl->gen_prefix[reg] + (entry - continuing), pp.per_tile, pp.per_tile_magic, in_tile);
                 int s_lo;
-                run_samples(pp, in_tile >> 8, s_lo, s_hi);
+                run_samples(pp, run_of_place(pp, in_tile), s_lo, s_hi);
                 sample = s_lo + (int)nth;
             } else {
                 sample = __float_as_int(b.w);
@@ -1329,7 +1389,7 @@ static void timing_collect(rt_context* ctx) {
 #define RT_CTL_GROUP 4
 static uint32_t magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
 // How a pass's samples are cut into runs that share a primary ray, and the divisors that go with it (see PathParams).
-static void set_runs(PathParams& pp, int run_len) {
+static void set_runs(PathParams& pp, int run_len, bool group_samples) {
     pp.run_len = run_len;
     pp.run_base = pp.first_sample / run_len;
     pp.n_runs = (pp.first_sample + pp.n_samples - 1) / run_len - pp.run_base + 1;
@@ -1339,6 +1399,13 @@ static void set_runs(PathParams& pp, int run_len) {
     pp.batch_magic = magic_of((uint32_t)pp.batch);
     pp.run_lanes = run_len < pp.n_samples ? run_len : pp.n_samples;      // no run of the pass has more samples than the pass
     pp.run_lanes_magic = magic_of((uint32_t)pp.run_lanes);
+    // one entry per sample: the samples of a batch side by side (groups of up to 16, a power of two that divides the batch)
+    pp.group_log2 = 0;
+    if (run_len == 1 && group_samples)
+        while (pp.group_log2 < 4u && pp.batch % (2 << pp.group_log2) == 0) pp.group_log2++;
+    pp.n_full_groups = (uint32_t)pp.n_runs >> pp.group_log2;
+    pp.group_rem = (uint32_t)pp.n_runs - (pp.n_full_groups << pp.group_log2);
+    pp.group_rem_magic = magic_of(pp.group_rem);
 }
 
 // One pass of the wavefront variant: all paths of samples [pp.first_sample, +pp.n_samples) of every pixel.  The
@@ -1436,7 +1503,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_
         // would take more than an eighth of a region
         const uint32_t longest_run = (uint32_t)std::min(pp.batch, R.pp.n_samples);
         const int run_len = (ctx->opt_share_primary && pp.batch > 1 && longest_run <= (cap / regions) / 8u) ? pp.batch : 1;
-        set_runs(R.pp, run_len);
+        set_runs(R.pp, run_len, std::getenv("RT_GROUP_SAMPLES") ? std::atoi(std::getenv("RT_GROUP_SAMPLES")) != 0 : true);
         R.entry_yield = (uint32_t)R.pp.run_lanes;      // the shading launch gives every new entry that many lanes, whatever its run is cut to
         R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_runs;
         // A pass whose entries all fit the first refill needs no look at the pool's population: iteration i traces segment
@@ -1689,6 +1756,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
     pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_lanes = 1; pp.run_lanes_magic = 0xFFFFFFFFu;
     pp.ring_tiles = 0; pp.ring_magic = 0; pp.width_magic = 0;                   // the linear slot layout, unless the wavefront pass says otherwise
+    pp.group_log2 = 0; pp.n_full_groups = 0; pp.group_rem = 0; pp.group_rem_magic = 0;
     if (wavefront && ctx->opt_hot_tune && ctx->hot_dirty && spp >= RT_TUNE_MIN_SPP && ctx->opt_hot_nodes > 0) {
         pp.first_sample = first_sample;
         const int rc = tune_hot_nodes(ctx, pp, s);

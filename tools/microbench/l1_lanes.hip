@@ -56,6 +56,43 @@ __global__ __launch_bounds__(256) void gather_coop(const float4* __restrict__ ta
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// Duplicate addresses: the lanes of a group of G read the SAME pieces of the SAME record (rays that coincide walk the same
+// nodes in lockstep).  Does the L1 charge such a load per lane or per distinct address?
+template <int G>
+__global__ __launch_bounds__(256) void gather_dup(const float4* __restrict__ tab, uint32_t mask, int iters, float* out) {
+    uint32_t s = (blockIdx.x * 256 + (threadIdx.x & ~(G - 1))) * 2654435761u + 12345u;       // one random stream per group
+    float acc = 0.0f;
+    uint32_t idx = lcg(s) & mask;
+    for (int it = 0; it < iters; it++) {
+        const float4* p = tab + (size_t)idx * 8;
+        float4 v[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) v[k] = p[k];
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += v[k].x;
+        idx = (lcg(s) ^ (uint32_t)(acc == 12345.678f)) & mask;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int G>
+static void run_dup(const float4* tab, uint32_t mask, float* out, int blocks, int iters) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(gather_dup<G>, dim3(blocks), dim3(256), 0, 0, tab, mask, 8, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(gather_dup<G>, dim3(blocks), dim3(256), 0, 0, tab, mask, iters, out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    const double wave_instr = (double)blocks * 4 * iters * 7;
+    const double clk = ms * 1e-3 * 2.4e9 * 256;
+    printf("table %8.3f MB 7 pieces, groups of %2d lanes read the same addresses: %8.3f ms  %6.2f clk per wave instruction (%d distinct addresses)\n",
+           (mask + 1.0) * 128 / 1e6, G, ms, clk / wave_instr, 64 / G);
+}
+
 template <int G>
 static void run_coop(const float4* tab, uint32_t mask, float* out, int blocks, int iters) {
     hipEvent_t a, b;
@@ -110,6 +147,11 @@ int main(int argc, char** argv) {
             run<7>(tab, n - 1, out, blocks, iters, first, "first");
             if (k < 64) run<7>(tab, n - 1, out, blocks, iters, spread, "spread");
         }
+        run_dup<1>(tab, n - 1, out, blocks, iters);
+        run_dup<2>(tab, n - 1, out, blocks, iters);
+        run_dup<4>(tab, n - 1, out, blocks, iters);
+        run_dup<16>(tab, n - 1, out, blocks, iters);
+        run_dup<64>(tab, n - 1, out, blocks, iters);
         run_coop<1>(tab, n - 1, out, blocks, iters);
         run_coop<2>(tab, n - 1, out, blocks, iters);
         run_coop<4>(tab, n - 1, out, blocks, iters);
