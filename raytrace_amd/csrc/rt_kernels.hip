@@ -1399,10 +1399,11 @@ static void set_runs(PathParams& pp, int run_len, bool group_samples) {
     pp.batch_magic = magic_of((uint32_t)pp.batch);
     pp.run_lanes = run_len < pp.n_samples ? run_len : pp.n_samples;      // no run of the pass has more samples than the pass
     pp.run_lanes_magic = magic_of((uint32_t)pp.run_lanes);
-    // one entry per sample: the samples of a batch side by side (groups of up to 16, a power of two that divides the batch)
+    // one entry per sample: the samples of a batch side by side, in groups of up to 16 -- a power of two that divides the
+    // batch and the pass's first sample, so that no group straddles two batches (its samples share one primary ray)
     pp.group_log2 = 0;
     if (run_len == 1 && group_samples)
-        while (pp.group_log2 < 4u && pp.batch % (2 << pp.group_log2) == 0) pp.group_log2++;
+        while (pp.group_log2 < 4u && pp.batch % (2 << pp.group_log2) == 0 && pp.first_sample % (2 << pp.group_log2) == 0) pp.group_log2++;
     pp.n_full_groups = (uint32_t)pp.n_runs >> pp.group_log2;
     pp.group_rem = (uint32_t)pp.n_runs - (pp.n_full_groups << pp.group_log2);
     pp.group_rem_magic = magic_of(pp.group_rem);
