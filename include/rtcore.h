@@ -170,6 +170,10 @@ enum {
                                  pass * 256 * 12 bytes: as many as this allows, never more than the frame has, at least one.  A ring
                                  shorter than the tiles in flight (about 2400 at the default pool size) holds new paths back; results
                                  do not depend on it */
+    RT_OPT_GROUP_SAMPLES = 22, /* wavefront with one walk per sample (RT_OPT_SHARE_PRIMARY off): 1 (default) = a tile's entries are ordered so that up to 16 samples
+                                 of a pixel's semantic batch -- which start along one and the same primary ray -- are traced by
+                                 neighbouring lanes (the vector L1 then serves four lanes that ask for one address in one clock instead
+                                 of four); 0 = sample after sample, 256 pixels each.  Order of work only: same image, same counts */
     RT_OPT_GPU_BVH = 17       /* 0 (default): rt_upload_scene re-packs the caller's trees, visiting order and hit records are upstream's bit
                                  for bit.  1: it reads only the triangle arrays (objects[i].bvh may be null) and builds ONE tree over all
                                  objects on the device (agglomeration in Morton order, rocPRIM sort and scans; 30 M triangles in under 0.1 s),

@@ -46,6 +46,7 @@ OPT_HOT_TUNE = 18
 OPT_SHARE_PRIMARY = 19
 OPT_SHARE_EQUAL = 20
 OPT_SLOT_RING_MB = 21
+OPT_GROUP_SAMPLES = 22
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 GROUP_ID_BYTES = 128

@@ -210,9 +210,6 @@ __device__ __forceinline__ bool slab(f2v p0, f2v p1, f2v p2, const RayD& r, floa
 }
 __device__ __forceinline__ bool slab(f4v a, f4v b, const RayD& r, float& t_near) { return slab(a.xy, a.zw, b.xy, r, t_near); }
 
-#ifndef RT_LEAF_NT
-#define RT_LEAF_NT 0
-#endif
 __device__ __forceinline__ float4 as_float4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 struct Hit {
@@ -398,17 +395,10 @@ struct Walker {
         // a one-triangle leaf do not read a second record: every 16-byte piece a lane reads is an L1 access
         const f4v* q = reinterpret_cast<const f4v*>(sc.isect + p);
         const bool pair = (cur & REF_PAIR) != 0;
-#if RT_LEAF_NT
-        // a triangle record is rarely wanted again soon, a node record is: the hint keeps the L1's lines for the nodes
-        const float4 a0 = as_float4(__builtin_nontemporal_load(q)), a1 = as_float4(__builtin_nontemporal_load(q + 1)), a2 = as_float4(__builtin_nontemporal_load(q + 2));
-        float4 b0, b1, b2;
-        if (pair) { b0 = as_float4(__builtin_nontemporal_load(q + 3)); b1 = as_float4(__builtin_nontemporal_load(q + 4)); b2 = as_float4(__builtin_nontemporal_load(q + 5)); }
-#else
         const float4 a0 = as_float4(q[0]), a1 = as_float4(q[1]), a2 = as_float4(q[2]);
         // left unset without a second triangle: a default taken from the first record would make the second fetch wait for the first
         float4 b0, b1, b2;
         if (pair) { b0 = as_float4(q[3]); b1 = as_float4(q[4]); b2 = as_float4(q[5]); }
-#endif
         tri_test(a0, a1, a2, p, r, h);
         if (pair) tri_test(b0, b1, b2, p + 1, r, h);
         cur = pop(h);
@@ -440,11 +430,7 @@ __device__ __forceinline__ v3 unit_sphere(uint32_t pixel, uint32_t sample, uint3
         philox(pixel, sample, bounce * 65536u + 1u + attempt, 0u, k0, k1, w0, w1, w2, w3);
         p = mk3(u01(w0) * 2.0f + (-1.0f), u01(w1) * 2.0f + (-1.0f), u01(w2) * 2.0f + (-1.0f));
         attempt++;
-#ifdef RT_EXP_ONE_ATTEMPT
-    } while (false);
-#else
     } while (vdot(p, p) >= 1.0f && attempt < 65535u);
-#endif
     return p;
 }
 

@@ -1063,6 +1063,7 @@ struct rt_context {
     uint32_t pool_cap_limit = 0xFFFFFFFFu;   // the largest pool this device had memory for, once an allocation has failed
     float* d_slots = nullptr;        // the sample slots of a pass (layouts: PathParams::ring_tiles), then one [n_pixel][3] carry plane
     size_t slots_bytes = 0;
+    int opt_group_samples = 1;                    // wavefront, one walk per sample: the samples of a batch in neighbouring lanes
     size_t slots_ring_bytes = (size_t)10 << 30;   // wavefront: what the ring of tile slots may take (less for a small frame: never more than the frame's tiles)
     int stack_slots = 1;
     uint64_t stats[8] = {0};
@@ -1224,6 +1225,7 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_PASS:
         if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "rt_set_option: pass must be 1..65536");
         ctx->opt_pass = value; return RT_OK;
+    case RT_OPT_GROUP_SAMPLES: ctx->opt_group_samples = value ? 1 : 0; return RT_OK;
     case RT_OPT_SLOT_RING_MB:
         if (value < 0 || value > (1 << 20)) return fail(RT_ERR_INVALID, "rt_set_option: slot ring must be 0..2^20 MiB");
         ctx->slots_ring_bytes = (size_t)value << 20; return RT_OK;
@@ -1504,7 +1506,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_
         // would take more than an eighth of a region
         const uint32_t longest_run = (uint32_t)std::min(pp.batch, R.pp.n_samples);
         const int run_len = (ctx->opt_share_primary && pp.batch > 1 && longest_run <= (cap / regions) / 8u) ? pp.batch : 1;
-        set_runs(R.pp, run_len, std::getenv("RT_GROUP_SAMPLES") ? std::atoi(std::getenv("RT_GROUP_SAMPLES")) != 0 : true);
+        set_runs(R.pp, run_len, ctx->opt_group_samples != 0);
         R.entry_yield = (uint32_t)R.pp.run_lanes;      // the shading launch gives every new entry that many lanes, whatever its run is cut to
         R.total = (unsigned long long)pp.tiles_x * pp.tiles_y * 256ull * (unsigned long long)R.pp.n_runs;
         // A pass whose entries all fit the first refill needs no look at the pool's population: iteration i traces segment

@@ -221,23 +221,24 @@ def test_wavefront_variant_bit_exact(gpu_ctx, name, kw, spp, batch, cap):
     (32, 64, 32, 18),       # batch 32: two groups of 16 share one primary ray
     (0, 48, 16, 10),        # pool of 1024 entries, smaller than one tile's group (4096 places)
 ])
-def test_samples_of_a_batch_side_by_side_bit_exact(gpu_ctx, monkeypatch, first, spp, batch, cap):
+def test_samples_of_a_batch_side_by_side_bit_exact(gpu_ctx, first, spp, batch, cap):
     """With one walk per sample (RT_OPT_SHARE_PRIMARY = 0) a tile's entries are laid out so that the samples of a semantic
     batch, which start with one and the same primary ray, sit in neighbouring lanes of the closest-hit kernel (groups of up
     to 16, a power of two that divides the batch).  Only the order of the entries changes: the image and every count are the
-    oracle's, and those of the run-after-run order (RT_GROUP_SAMPLES=0)."""
+    oracle's, and those of the sample-after-sample order (RT_OPT_GROUP_SAMPLES = 0)."""
     p = Pair(gpu_ctx, scene.material_box(width=70, height=45, n_samples=first + spp))
     ref, rcnt = p.oracle.render(orc.make_params(p.cfg, SEED, batch), first, spp)
     gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
     gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, cap)
     try:
         got, gcnt = p.gpu_render(first, spp, batch)
-        monkeypatch.setenv("RT_GROUP_SAMPLES", "0")
+        gpu_ctx.set_option(capi.OPT_GROUP_SAMPLES, 0)
         plain, pcnt = p.gpu_render(first, spp, batch)
-        monkeypatch.delenv("RT_GROUP_SAMPLES")
+        gpu_ctx.set_option(capi.OPT_GROUP_SAMPLES, 1)
         gpu_ctx.set_option(capi.OPT_PASS, 9)                        # passes that cut through groups and batches
         passes, _ = p.gpu_render(first, spp, batch)
     finally:
+        gpu_ctx.set_option(capi.OPT_GROUP_SAMPLES, 1)
         gpu_ctx.set_option(capi.OPT_PASS, 1024)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
         gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
