@@ -237,6 +237,19 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
                 int max_depth, const float ambient[3], float russian_roulette,
                 float* d_output, void* stream);
 
+/* rt_raytrace for a caller with one thread and something else to do.  Upstream's raytrace() is a kernel launch that returns
+ * at once and Worker::render_ waits for it afterwards (csrc/worker.cpp:80-89); rt_raytrace in wavefront mode cannot return
+ * before its passes have drained, because the host drives the stages.  rt_raytrace_start takes the same arguments (`ambient`
+ * is copied), hands the call to a thread of the library and returns; rt_raytrace_wait joins that thread and returns the
+ * call's status (rt_last_error then has its text in the waiting thread).  After a successful wait the result is complete once
+ * `stream` is synchronised, as after rt_raytrace.  Between the two, the context and `stream` belong to the call: no other
+ * entry point may be given this context (rt_raytrace_start itself answers RT_ERR_INVALID while a call is outstanding).
+ * rt_raytrace_wait with nothing outstanding returns RT_OK; rt_destroy waits by itself. */
+int rt_raytrace_start(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch,
+                      int max_depth, const float ambient[3], float russian_roulette,
+                      float* d_output, void* stream);
+int rt_raytrace_wait(rt_context* ctx);
+
 /* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same result bit for bit as rt_raytrace,
  * but the call allocates, creates and frees nothing: the sample slots between the path kernel and the ordered sum

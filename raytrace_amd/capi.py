@@ -66,7 +66,7 @@ class RtTransform(C.Structure):
 
 EXPORTS = [
     "rt_last_error", "rt_abi_version", "rt_build_bvh", "rt_apply_transform", "rt_create", "rt_destroy", "rt_set_option",
-    "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_raytrace_static", "rt_post_process", "rt_primary_rays",
+    "rt_upload_scene", "rt_init_randstate", "rt_setup_raytrace", "rt_raytrace", "rt_raytrace_start", "rt_raytrace_wait", "rt_raytrace_static", "rt_post_process", "rt_primary_rays",
     "rt_closest_hit", "rt_get_counters", "rt_reset_counters", "rt_get_timing", "rt_scene_stats", "rt_check_node_numbering", "rt_device_alloc", "rt_device_free",
     "rt_device_zero", "rt_copy_to_host", "rt_copy_to_device", "rt_synchronize",
     "rt_get_device", "rt_partition_samples", "rt_group_unique_id", "rt_group_create", "rt_group_destroy", "rt_reduce_to_root",
@@ -107,6 +107,8 @@ def load():
         "rt_setup_raytrace": [vp, i32, i32, fp, fp, fp, f32],
         "rt_raytrace": [vp, i32, i32, i32, i32, i32, fp, f32, vp, vp],
         "rt_raytrace_static": [vp, i32, i32, i32, i32, i32, fp, f32, vp, vp],
+        "rt_raytrace_start": [vp, i32, i32, i32, i32, i32, fp, f32, vp, vp],
+        "rt_raytrace_wait": [vp],
         "rt_post_process": [vp, i32, i32, f32, vp, vp],
         "rt_primary_rays": [vp, u32, vp, vp],
         "rt_closest_hit": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -228,6 +230,13 @@ class Context:
 
     def raytrace(self, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, rr, d_out, stream=0):
         check(self.lib.rt_raytrace(self.h, n_pixel, first_sample, spp, semantic_batch, max_depth, f3(ambient), rr, d_out, stream))
+
+    def raytrace_start(self, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, rr, d_out, stream=0):
+        """rt_raytrace handed to a thread of the library; returns at once.  The context belongs to the call until raytrace_wait."""
+        check(self.lib.rt_raytrace_start(self.h, n_pixel, first_sample, spp, semantic_batch, max_depth, f3(ambient), rr, d_out, stream))
+
+    def raytrace_wait(self):
+        check(self.lib.rt_raytrace_wait(self.h))
 
     def raytrace_static(self, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, rr, d_out, stream=0):
         """rt_raytrace without any allocation: sample slots in the library's static device array."""

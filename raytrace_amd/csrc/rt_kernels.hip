@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_build.h"
@@ -1067,6 +1068,10 @@ struct rt_context {
     size_t slots_ring_bytes = (size_t)10 << 30;   // wavefront: what the ring of tile slots may take (less for a small frame: never more than the frame's tiles)
     int stack_slots = 1;
     uint64_t stats[8] = {0};
+    // rt_raytrace_start / rt_raytrace_wait: the call a library thread is driving, and how it ended
+    std::thread job;
+    int job_status = RT_OK;
+    std::string job_error;
 };
 
 static void free_scene(rt_context* c) {
@@ -1166,6 +1171,7 @@ int rt_create(int device_id, rt_context** out) {
 
 int rt_destroy(rt_context* ctx) {
     if (!ctx) return RT_OK;
+    if (ctx->job.joinable()) ctx->job.join();
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_scene(ctx);
@@ -1794,6 +1800,34 @@ int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int sem
                 float russian_roulette, float* d_output, void* stream) {
     return raytrace_body("rt_raytrace", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, russian_roulette, d_output,
                          (hipStream_t)stream, nullptr, 0);
+}
+
+int rt_raytrace_start(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
+                      float russian_roulette, float* d_output, void* stream) {
+    if (!ctx || !ambient) return fail(RT_ERR_INVALID, "rt_raytrace_start: null argument");
+    if (ctx->job.joinable()) return fail(RT_ERR_INVALID, "rt_raytrace_start: the context is still driving a call (rt_raytrace_wait first)");
+    const float amb[3] = {ambient[0], ambient[1], ambient[2]};
+    ctx->job_status = RT_OK;
+    ctx->job_error.clear();
+    try {
+        ctx->job = std::thread([=]() {
+            const int rc = raytrace_body("rt_raytrace_start", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, amb, russian_roulette,
+                                         d_output, (hipStream_t)stream, nullptr, 0);
+            ctx->job_status = rc;
+            if (rc != RT_OK) ctx->job_error = g_last_error;       // the error text is per thread: hand it to the one that waits
+        });
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_DEVICE, std::string("rt_raytrace_start: cannot start a thread: ") + e.what());
+    }
+    return RT_OK;
+}
+
+int rt_raytrace_wait(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_raytrace_wait: null argument");
+    if (!ctx->job.joinable()) return RT_OK;                       // nothing outstanding
+    ctx->job.join();
+    if (ctx->job_status != RT_OK) return fail(ctx->job_status, ctx->job_error);
+    return RT_OK;
 }
 
 int rt_raytrace_static(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],

@@ -250,6 +250,40 @@ def test_samples_of_a_batch_side_by_side_bit_exact(gpu_ctx, first, spp, batch, c
     assert gcnt[capi.CNT_BOX_TESTS] == pcnt[capi.CNT_BOX_TESTS] and gcnt[capi.CNT_NODE_VISITS] == pcnt[capi.CNT_NODE_VISITS]
 
 
+def test_started_call_returns_at_once_and_gives_the_same_buffer(gpu_ctx):
+    """rt_raytrace_start hands the call to a thread of the library: it returns long before the frame is done (the blocking
+    call cannot, in wavefront mode: the host drives the stages), a second start on the busy context is refused, and after
+    rt_raytrace_wait the buffer is the blocking call's bit for bit.  A call that fails reports through the wait."""
+    import time
+    torch = _torch()
+    p = Pair(gpu_ctx, scene.formula1(width=640, height=400, n_samples=128, detail=0.2, tex_size=64))
+    npix, cfg = p.cfg.width * p.cfg.height, p.cfg
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    try:
+        t0 = time.perf_counter()
+        want, _ = p.gpu_render(0, 128, 16, counters=False)
+        blocking = time.perf_counter() - t0
+        d = torch.zeros(npix, 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu_ctx.raytrace_start(npix, 0, 128, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+        started = time.perf_counter() - t0
+        with pytest.raises(capi.RtError, match="still driving"):
+            gpu_ctx.raytrace_start(npix, 0, 128, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+        gpu_ctx.raytrace_wait()
+        gpu_ctx.synchronize()
+        got = d.cpu().numpy()
+        assert same_f32(got, want)
+        assert started < 0.25 * blocking, (started, blocking)
+        gpu_ctx.raytrace_wait()                                     # nothing outstanding: fine
+        # first_sample not a multiple of the batch: the started call's failure comes out of the wait, with its text
+        gpu_ctx.raytrace_start(npix, 3, 16, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
+        with pytest.raises(capi.RtError, match="multiple"):
+            gpu_ctx.raytrace_wait()
+    finally:
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+
+
 def test_wavefront_depth_zero_and_glass(gpu_ctx):
     gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
     try:
