@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--slot-ring-mb", type=int, default=-1, help="MiB the ring of tile slots may take (default: library default)")
     ap.add_argument("--share-equal", type=int, default=-1, help="1/0: samples that leave a mirror or glass along one ray share its walk / every continued path is walked (default: 0 for the headline, library default beside it)")
     ap.add_argument("--share-primary", type=int, default=-1, help="1/0: one closest-hit walk per pixel and semantic batch / one per sample (default: library default)")
-    ap.add_argument("--hot-tune", type=int, default=-1, help="1/0: number the LDS-resident node records by measured visits (default: library default)")
+    ap.add_argument("--hot-tune", type=int, default=-1, help="2/1/0: number the LDS-resident node records by measured visits per band of the picture / of the whole view / not at all (default: library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the scene tree on the device (RT_OPT_GPU_BVH) instead of re-packing upstream's trees")
     ap.add_argument("--depth", type=int, default=0, help="override the scene's max depth (experiments only: not the headline workload)")
     args = ap.parse_args()

@@ -150,10 +150,13 @@ enum {
                                  one pipeline's kernels fill the CUs another's closest-hit launch has already left (default 1; 1 or 2; 2 measured slower);
                                  scheduling only */
     RT_OPT_WF_BURST = 9,      /* wavefront: inner-node trips between two looks at leaves and idle lanes (default 4); scheduling only */
-    RT_OPT_HOT_TUNE = 18,     /* wavefront: 1 (default) = before the first call of at least 64 samples per pixel after a scene upload or a camera
+    RT_OPT_HOT_TUNE = 18,     /* wavefront: 1 = before the first call of at least 64 samples per pixel after a scene upload or a camera
                                  change, one sample per pixel is traced to count the visits of the 4096 node records nearest the root, and
                                  those records are renumbered by falling count, so that the records the closest-hit kernel keeps in LDS
-                                 (RT_OPT_HOT_NODES) are the ones this view enters most; 0 = static order (largest boxes first).
+                                 (RT_OPT_HOT_NODES) are the ones this view enters most; 2 (default) = the visits are counted per band of
+                                 the picture as well (a pass starts its paths tile row after tile row, so the paths in flight belong to
+                                 one band at a time) and the closest-hit launches read those records from a copy numbered for the band
+                                 in flight (up to 64 copies of 512 KB); 0 = static order (largest boxes first).
                                  Scheduling only: node numbers are addresses */
     RT_OPT_SHARE_PRIMARY = 19, /* wavefront: 1 (default) = the samples of a semantic batch, which upstream starts with one and the same jittered
                                  primary ray (cuda/raytrace.cu:210, its README's "Hints"), share ONE closest-hit walk for it: a new pool entry

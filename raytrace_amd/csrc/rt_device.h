@@ -41,6 +41,7 @@ struct PathParams {
     int xcd_remap;
     int lds_slots;                        // stack levels kept in LDS
     int sort_rays;                        // unused (the compaction no longer orders by direction octant)
+    int hist_bands;                       // calibration pass only: the histogram has this many parts, one per band of tile rows (0: one part)
     uint32_t* hist;                       // calibration pass only: per-node visit counts (see TravCounters), else null
     // wavefront: divisors the refill and the shading kernel divide path numbers by, with floor(2^32 / divisor) beside them
     uint32_t per_tile, per_tile_magic;    // pool entries one 16x16 tile starts in this pass = n_runs * 256
@@ -272,16 +273,23 @@ struct Walker {
     int stride, lds_slots;
     lds_float4* hot;
     uint32_t n_hot;
+    // The first `top_n` records may be read from a renumbered copy of their own at `top` (numbers are only addresses;
+    // `root_ref` is the root's number in that copy): the copy whose first n_hot records are the ones the rays of the part
+    // of the picture now in flight enter most.  top_n == 0: one array, the scene's.
+    const Node4* top;
+    uint32_t top_n, root_ref;
     uint2* spill;                  // RT_SPILL_SLOTS private entries owned by the caller (kept out of this struct so that its scalars stay in registers)
 
     __device__ __forceinline__ void init(lds_uint2* stack_, int stride_, int lds_slots_, uint2* spill_) {
         stack = stack_; stride = stride_; lds_slots = lds_slots_; spill = spill_; cur = REF_NONE; sp = 0;
         hot = nullptr; n_hot = 0;
+        top = nullptr; top_n = 0; root_ref = REF_NONE;
     }
 
     // The first `n_hot_` node records (breadth-first numbering: the ones nearest to the root, which take more than
     // half of all visits) have been copied to LDS at `hot_`, RT_HOT_STRIDE bytes apart.
     __device__ __forceinline__ void set_hot(lds_float4* hot_, uint32_t n_hot_) { hot = hot_; n_hot = n_hot_; }
+    __device__ __forceinline__ void set_top(const Node4* top_, uint32_t top_n_, uint32_t root_ref_) { top = top_; top_n = top_n_; root_ref = root_ref_; }
 
     __device__ __forceinline__ void begin(const SceneDev& sc, const RayD& r, Hit& h, TravCounters& tc) {
         sp = 0;
@@ -317,7 +325,7 @@ struct Walker {
                 const float4* q = reinterpret_cast<const float4*>(sc.isect + sc.last_tri);
                 tri_test(q[0], q[1], q[2], sc.last_tri, r, h);
             }
-        } else if (!still && slab(a, b, r, tn)) first = sc.root.ref;
+        } else if (!still && slab(a, b, r, tn)) first = top_n ? root_ref : sc.root.ref;
         return first;
     }
 
@@ -352,7 +360,7 @@ struct Walker {
             const lds_float4* q = hot + cur * (RT_HOT_STRIDE / 16);
             q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
         } else {
-            const f4v* q = reinterpret_cast<const f4v*>(sc.nodes + cur);
+            const f4v* q = reinterpret_cast<const f4v*>((cur < top_n ? top : sc.nodes) + cur);
             q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
         }
         const uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(RT_BLOCK) void path_kernel(SceneDev sc, PathParams 
     uint32_t n_rays = 0, n_shaded = 0, n_tex = 0, n_paths = 0;
     TravCounters tc = {};
     tc.hist = pp.hist;
+    if (pp.hist && pp.hist_bands) tc.hist += (size_t)(ty * pp.hist_bands / pp.tiles_y) * RT_HIST_NODES;      // the band of this tile row
 
     const int pass_end = pp.first_sample + pp.n_samples;
     int sample = pp.first_sample + chunk_id * pp.chunk;
@@ -233,7 +234,8 @@ struct WfCtl {
     // the slot ring (PathParams::ring_tiles): the cursor after each of the last RT_CURSOR_HISTORY refills, the tiles whose
     // slots have been summed, and the range the ordered sum launched behind this refill is to take
     unsigned long long cursor_after[RT_CURSOR_HISTORY];
-    uint32_t acc_done, acc_from, acc_to, pad_;
+    uint32_t acc_done, acc_from, acc_to;
+    uint32_t band;                  // which renumbered copy of the first node records the closest-hit launch reads (the band of tile rows now in flight)
 };
 #define RT_CTL_HEAD_BYTES 80
 static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads back exactly the head of the control block");
@@ -248,7 +250,7 @@ static_assert(offsetof(WfCtl, queue_next) == RT_CTL_HEAD_BYTES, "the host reads 
 // ring_tiles == 0: no ring, nothing is summed before the pass has drained.
 __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int nxt, unsigned long long total, uint32_t regions, uint32_t region_cap,
                                                                  uint32_t per_tile, uint32_t entry_yield, uint32_t ring_tiles, uint32_t lifetime,
-                                                                 unsigned long long* counters) {
+                                                                 uint32_t tiles_x, uint32_t tiles_y, uint32_t n_bands, unsigned long long* counters) {
     __shared__ uint32_t scan[RT_REGIONS_MAX];
     const uint32_t r = threadIdx.x;
     if (r == 0 && ctl->n_worked) {
@@ -329,6 +331,13 @@ __global__ __launch_bounds__(RT_REGIONS_MAX) void wf_plan_kernel(WfCtl* ctl, int
         ctl->cursor += n;
         ctl->cursor_after[it % RT_CURSOR_HISTORY] = ctl->cursor;
         ctl->acc_from = acc_done; ctl->acc_to = acc_to; ctl->acc_done = acc_to;
+        // Most of the pool are entries of this refill and the one before: the tile row this refill starts in names the
+        // band of the picture the launch works on (bands: n_bands equal shares of the tile rows, as the calibration cut
+        // them).  Half a pool or a pool further back: 0.2 and 1.2 points fewer visits served from LDS.
+        if (n_bands) {
+            const uint32_t row = (uint32_t)min((unsigned long long)(tiles_y - 1u), cursor_now / per_tile / tiles_x);
+            ctl->band = min(n_bands - 1u, row * n_bands / tiles_y);
+        }
         ctl->t_first = ~0ull; ctl->t_last = 0; ctl->t_end_sum = 0; ctl->n_worked = 0;
     }
     if (r < RT_QUEUES) ctl->queue_next[r * RT_QUEUE_STRIDE] = 0;
@@ -574,9 +583,13 @@ template <bool COUNT, bool VOTE>
 __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_extend_kernel(SceneDev sc, WfCtl* ctl, WfPools pools, int nxt,
                                                              int lds_slots, uint32_t chunk, int node_burst, uint32_t n_hot,
                                                              int vote_leaf_weight, int refill_min, float cam_x, float cam_y, float cam_z,
-                                                             uint32_t regions, uint32_t log2_region_cap, unsigned long long* counters) {
+                                                             uint32_t regions, uint32_t log2_region_cap, unsigned long long* counters,
+                                                             const Node4* __restrict__ band_nodes, const uint32_t* __restrict__ band_roots, uint32_t top_n) {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     lds_uint2* stack = (lds_uint2*)lds_stack + threadIdx.x;
+    // top_n > 0: the first top_n node records are read from the copy numbered for the band of the picture in flight
+    const uint32_t band = top_n ? ctl->band : 0u;
+    const Node4* top = top_n ? band_nodes + (size_t)band * RT_HIST_NODES : sc.nodes;
     // behind the stacks, inside the one dynamic LDS block: copies of the first n_hot node records
     const uint32_t block = blockDim.x;
     lds_float4* hot = (lds_float4*)((lds_uint2*)lds_stack + (size_t)lds_slots * block);
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     TravCounters tc = {};
     for (uint32_t k = threadIdx.x; k < n_hot * 7u; k += block) {
         const uint32_t node = k / 7u, piece = k - node * 7u;
-        const float4 v = reinterpret_cast<const float4*>(sc.nodes)[node * 8u + piece];
+        const float4 v = reinterpret_cast<const float4*>(top)[node * 8u + piece];
         f4v o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
         hot[node * (RT_HOT_STRIDE / 16) + piece] = o;
     }
@@ -598,6 +611,7 @@ __global__ __launch_bounds__(RT_EXTEND_BLOCK_MAX) RT_EXTEND_OCCUPANCY void wf_ex
     Walker<COUNT> w;
     w.init(stack, (int)block, lds_slots, spill);
     w.set_hot(hot, n_hot);
+    if (top_n) w.set_top(top, top_n, band_roots[band]);
     RayD r;
     ray_set(r, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f));
     Hit h;
@@ -987,6 +1001,20 @@ __global__ __launch_bounds__(RT_BLOCK) void permute_nodes_kernel(const Node4* __
     out[perm[i]] = nd;
 }
 
+// The same for several numberings at once: copy blockIdx.y of the first k records, numbered by perms[blockIdx.y][.],
+// RT_HIST_NODES records apart in `out`; the array itself is left as it is.
+__global__ __launch_bounds__(RT_BLOCK) void permute_bands_kernel(const Node4* __restrict__ nodes, uint32_t k, const uint32_t* __restrict__ perms, Node4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= k) return;
+    const uint32_t* perm = perms + (size_t)blockIdx.y * RT_HIST_NODES;
+    Node4 nd = nodes[i];
+    for (int slot = 0; slot < 4; slot++) {
+        const uint32_t r = nd.ref[slot];
+        if (r != REF_NONE && !(r & REF_LEAF) && r < k) nd.ref[slot] = perm[r];
+    }
+    out[(size_t)blockIdx.y * RT_HIST_NODES + perm[i]] = nd;
+}
+
 // ---------------------------------------------------------------------------
 // context and C ABI
 // ---------------------------------------------------------------------------
@@ -1019,9 +1047,15 @@ struct rt_context {
     uint64_t seed = 0;
     int width = 0, height = 0;
     int opt_counters = 0, opt_xcd = 1;
-    int opt_hot_tune = 1;            // wavefront: number the node records by measured visits before a frame (one calibration sample per pixel)
+    int opt_hot_tune = 2;            // wavefront: number the node records by measured visits before a frame (one calibration sample per pixel); 2 = per band of the picture as well
     bool hot_dirty = true;           // scene or camera changed since the node numbering was last tuned
     void* d_tune = nullptr;          // calibration scratch: visit counts, throw-away counters, permutation, a copy of the candidate records
+    // RT_OPT_HOT_TUNE = 2: one renumbered copy of the first node records per band of the picture (the calibration counts
+    // visits band by band), so that the records in LDS are the ones the rays in flight enter most
+    Node4* d_band_nodes = nullptr;   // [RT_BANDS_MAX][RT_HIST_NODES]
+    uint32_t* d_band_roots = nullptr;   // the root's number in each copy
+    uint32_t n_bands = 0;            // copies that are valid for the present scene and camera (0: none)
+    uint32_t band_records = 0;       // records in each copy
     int opt_share_equal = 1;         // wavefront: samples of a pixel that leave a mirror or glass along one and the same ray share that ray's walk too
     int opt_share_primary = 1;       // wavefront: one closest-hit query per pixel and semantic batch (its samples share the primary ray)
     int opt_gpu_bvh = 0;             // 1 = rt_upload_scene builds its own tree on the device instead of re-packing the caller's
@@ -1178,6 +1212,8 @@ int rt_destroy(rt_context* ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_tune) (void)hipFree(ctx->d_tune);
+    if (ctx->d_band_nodes) (void)hipFree(ctx->d_band_nodes);
+    if (ctx->d_band_roots) (void)hipFree(ctx->d_band_roots);
     free_pools(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -1191,7 +1227,10 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     case RT_OPT_XCD_REMAP: ctx->opt_xcd = value ? 1 : 0; return RT_OK;
     case RT_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; return RT_OK;
     case RT_OPT_GPU_BVH: ctx->opt_gpu_bvh = value ? 1 : 0; return RT_OK;
-    case RT_OPT_HOT_TUNE: ctx->opt_hot_tune = value ? 1 : 0; return RT_OK;
+    case RT_OPT_HOT_TUNE:
+        if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "rt_set_option: hot-node tuning must be 0, 1 or 2");
+        if (value != ctx->opt_hot_tune) { ctx->hot_dirty = true; ctx->n_bands = 0; }
+        ctx->opt_hot_tune = value; return RT_OK;
     case RT_OPT_SHARE_PRIMARY: ctx->opt_share_primary = value ? 1 : 0; return RT_OK;
     case RT_OPT_SHARE_EQUAL: ctx->opt_share_equal = value ? 1 : 0; return RT_OK;
     case RT_OPT_MODE:
@@ -1332,6 +1371,7 @@ int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, co
     ctx->stats[4] = (uint64_t)n_objects;
     ctx->have_scene = true;
     ctx->hot_dirty = true;
+    ctx->n_bands = 0;
     return RT_OK;
 }
 
@@ -1351,7 +1391,7 @@ int rt_setup_raytrace(rt_context* ctx, int width, int height, const float camera
     const CameraFrame frame = camera_frame(width, height, camera_pos, camera_dir, camera_up, fov_radians);
     // the node numbering was tuned for a view: only another view asks for another calibration pass (a worker sets the
     // same camera again before every frame)
-    if (!ctx->have_camera || std::memcmp(&frame, &ctx->cam, sizeof frame) != 0) ctx->hot_dirty = true;
+    if (!ctx->have_camera || std::memcmp(&frame, &ctx->cam, sizeof frame) != 0) { ctx->hot_dirty = true; ctx->n_bands = 0; }
     ctx->cam = frame;
     ctx->width = width;
     ctx->height = height;
@@ -1555,7 +1595,7 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_
                 }
             }
             hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(RT_REGIONS_MAX), 0, ls, L.d_ctl, nxt, R.total, regions, cap / regions, R.pp.per_tile, R.entry_yield,
-                               follow ? ring_tiles : 0u, lifetime, ctx->d_counters);
+                               follow ? ring_tiles : 0u, lifetime, (uint32_t)R.pp.tiles_x, (uint32_t)R.pp.tiles_y, ctx->n_bands, ctx->d_counters);
             // the tiles whose last path has ended are summed now, before any later tile's paths write to their places in the ring
             // (On a stream of its own beside the closest-hit launch the sum cost more than it hid: it pushes 30 GB per pass
             // through the L2 the walk lives in -- closest-hit launches +4 %.)
@@ -1570,7 +1610,8 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_
                                                 : (ctx->opt_wf_vote ? wf_extend_kernel<false, true> : wf_extend_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, egrid, eblock, elds, ls, ctx->dev, L.d_ctl, L.pools, nxt,
                                    slots_lds, rpb, ctx->opt_wf_burst, n_hot, ctx->opt_wf_vote, ctx->opt_wf_refill, R.pp.cam.pos[0], R.pp.cam.pos[1], R.pp.cam.pos[2],
-                                   regions, log2_region_cap, ctx->d_counters);
+                                   regions, log2_region_cap, ctx->d_counters, (const Node4*)ctx->d_band_nodes, (const uint32_t*)ctx->d_band_roots,
+                                   ctx->n_bands ? ctx->band_records : 0u);
             }
             timing_end(ctx, tke, ls);
             HIP_TRY(hipGetLastError());
@@ -1618,17 +1659,18 @@ static int wavefront_pass(rt_context* ctx, PathParams pp, hipStream_t s, uint32_
 // are only addresses: no result changes.  Costs about ten milliseconds and a stream
 // synchronisation, so it runs once per scene and camera, and only for calls of at least RT_TUNE_MIN_SPP samples.
 #define RT_TUNE_MIN_SPP 64
+// RT_OPT_HOT_TUNE = 2 goes one step further.  A pass starts its paths tile row after tile row, so at any moment the pools
+// hold paths of a band of the picture a few tile rows tall, and the records those paths enter most are not the whole
+// view's: the calibration counts visits per band (up to RT_BANDS_MAX equal shares of the tile rows), and for every band a
+// copy of the first records is numbered by the visits of that band and its two neighbours.  The refill planner names
+// the band in flight in the control block and the closest-hit launch reads the first records -- the ones it copies to LDS
+// first of all -- from that band's copy.  Measured on formula1: 51 % of node visits served from LDS with one numbering,
+// 55-58 % with the band's own.
+#define RT_BANDS_MAX 64u
 static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(RT_HIST_NODES, ctx->stats[1]);
+    ctx->n_bands = 0;
     if (k < 2) return RT_OK;
-    const size_t hist_bytes = RT_HIST_NODES * sizeof(uint32_t), cnt_bytes = RT_CNT_WORDS * sizeof(unsigned long long);
-    const size_t perm_at = hist_bytes + cnt_bytes, copy_at = perm_at + hist_bytes;
-    if (!ctx->d_tune) HIP_TRY(hipMalloc(&ctx->d_tune, copy_at + RT_HIST_NODES * sizeof(Node4)));
-    char* base = (char*)ctx->d_tune;
-    uint32_t* d_hist = (uint32_t*)base;
-    uint32_t* d_perm = (uint32_t*)(base + perm_at);
-    Node4* d_copy = (Node4*)(base + copy_at);
-    HIP_TRY(hipMemsetAsync(base, 0, hist_bytes + cnt_bytes, s));
     pp.n_samples = 1;
     pp.chunk = 1;
     pp.n_chunks = 1;
@@ -1639,14 +1681,29 @@ static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
     pp.n_pixel = pp.cam.width * pp.cam.height;
     pp.tiles_x = (pp.cam.width + 15) / 16;
     pp.tiles_y = (pp.cam.height + 15) / 16;
+    uint32_t bands = ctx->opt_hot_tune >= 2 ? std::min<uint32_t>(RT_BANDS_MAX, (uint32_t)pp.tiles_y) : 1u;
+    const size_t hist_bytes = (size_t)RT_BANDS_MAX * RT_HIST_NODES * sizeof(uint32_t), cnt_bytes = RT_CNT_WORDS * sizeof(unsigned long long);
+    const size_t perm_at = hist_bytes + cnt_bytes, copy_at = perm_at + hist_bytes;       // the permutations take as much room as the counts
+    if (!ctx->d_tune) HIP_TRY(hipMalloc(&ctx->d_tune, copy_at + RT_HIST_NODES * sizeof(Node4)));
+    char* base = (char*)ctx->d_tune;
+    uint32_t* d_hist = (uint32_t*)base;
+    uint32_t* d_perm = (uint32_t*)(base + perm_at);
+    Node4* d_copy = (Node4*)(base + copy_at);
+    HIP_TRY(hipMemsetAsync(base, 0, hist_bytes + cnt_bytes, s));
     pp.counters = (unsigned long long*)(base + hist_bytes);      // the calibration's rays are not the frame's: counted apart and dropped
     pp.hist = d_hist;
+    pp.hist_bands = bands > 1u ? (int)bands : 0;
     const long long nblocks = (long long)pp.tiles_x * pp.tiles_y;
     hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)nblocks), dim3(RT_BLOCK), stack_bytes(ctx), s, ctx->dev, pp);
     HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> hist(k), order(k), perm(k);
-    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> counts((size_t)bands * RT_HIST_NODES);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_hist, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // the whole view's numbering: the array itself, which every other kernel reads
+    std::vector<uint64_t> hist(k, 0);
+    for (uint32_t b = 0; b < bands; b++)
+        for (uint32_t i = 0; i < k; i++) hist[i] += counts[(size_t)b * RT_HIST_NODES + i];
+    std::vector<uint32_t> order(k), perm(k);
     for (uint32_t i = 0; i < k; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&hist](uint32_t a, uint32_t b) { return hist[a] > hist[b]; });
     bool moved = false;
@@ -1656,11 +1713,40 @@ static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
         hipLaunchKernelGGL(permute_nodes_kernel, dim3((k + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, s, (const Node4*)ctx->d_nodes, k, (const uint32_t*)d_perm, d_copy);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctx->d_nodes, d_copy, (size_t)k * sizeof(Node4), hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));                         // `perm` leaves scope
+        HIP_TRY(hipStreamSynchronize(s));                         // d_perm is written again below
         uint32_t& root = ctx->dev.root.ref;
         if (root != REF_NONE && !(root & REF_LEAF) && root < k) root = perm[root];
     }
     ctx->hot_dirty = false;
+    if (bands < 2u) return RT_OK;
+    // one copy per band, numbered by the visits of the band and its neighbours (counts indexed by the numbers the array has now)
+    if (!ctx->d_band_nodes) HIP_TRY(hipMalloc((void**)&ctx->d_band_nodes, (size_t)RT_BANDS_MAX * RT_HIST_NODES * sizeof(Node4)));
+    if (!ctx->d_band_roots) HIP_TRY(hipMalloc((void**)&ctx->d_band_roots, RT_BANDS_MAX * sizeof(uint32_t)));
+    const int window = 1;          // a band alone: -0.5 points of LDS-served visits; two neighbours each side: -0.6
+    std::vector<uint32_t> perms((size_t)bands * RT_HIST_NODES, 0u), roots(RT_BANDS_MAX, REF_NONE);
+    std::vector<uint64_t> mine(k);
+    const uint32_t root_now = ctx->dev.root.ref;
+    for (uint32_t b = 0; b < bands; b++) {
+        std::fill(mine.begin(), mine.end(), 0ull);
+        for (int nb = (int)b - window; nb <= (int)b + window; nb++) {
+            if (nb < 0 || nb >= (int)bands) continue;
+            const uint32_t* c = counts.data() + (size_t)nb * RT_HIST_NODES;
+            for (uint32_t i = 0; i < k; i++) mine[perm[i]] += (nb == (int)b ? 2ull : 1ull) * c[i];     // perm: old number -> number in the array now
+        }
+        for (uint32_t i = 0; i < k; i++) order[i] = i;
+        // ties (records the band never entered) keep the whole view's order
+        std::stable_sort(order.begin(), order.end(), [&mine](uint32_t a, uint32_t c) { return mine[a] > mine[c]; });
+        uint32_t* pb = perms.data() + (size_t)b * RT_HIST_NODES;
+        for (uint32_t at = 0; at < k; at++) pb[order[at]] = at;
+        roots[b] = (root_now != REF_NONE && !(root_now & REF_LEAF) && root_now < k) ? pb[root_now] : root_now;
+    }
+    HIP_TRY(hipMemcpyAsync(d_perm, perms.data(), perms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_band_roots, roots.data(), RT_BANDS_MAX * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(permute_bands_kernel, dim3((k + RT_BLOCK - 1) / RT_BLOCK, bands), dim3(RT_BLOCK), 0, s, (const Node4*)ctx->d_nodes, k, (const uint32_t*)d_perm, ctx->d_band_nodes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));                             // `perms` and `roots` leave scope
+    ctx->n_bands = bands;
+    ctx->band_records = k;
     return RT_OK;
 }
 
@@ -1761,7 +1847,7 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
     pp.chunk = ctx->opt_chunk;
     pp.lds_slots = lds_slots(ctx);
     pp.sort_rays = ctx->opt_wf_sort;
-    pp.hist = nullptr;
+    pp.hist = nullptr; pp.hist_bands = 0;
     pp.per_tile = pp.per_tile_magic = pp.tiles_x_magic = pp.batch_magic = 0;     // set per pass by the wavefront variant
     pp.run_len = 1; pp.run_base = 0; pp.n_runs = 0; pp.run_lanes = 1; pp.run_lanes_magic = 0xFFFFFFFFu;
     pp.ring_tiles = 0; pp.ring_magic = 0; pp.width_magic = 0;                   // the linear slot layout, unless the wavefront pass says otherwise

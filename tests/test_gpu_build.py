@@ -239,7 +239,7 @@ def test_device_build_falls_back_when_the_agglomeration_crawls(capfd):
 
 
 def test_hot_node_tuning_on_a_device_built_tree_moves_records_not_results():
-    """RT_OPT_GPU_BVH with RT_OPT_HOT_TUNE 0 and 1 at 64 spp (the calibration only runs from 64 samples per call on): the
+    """RT_OPT_GPU_BVH with RT_OPT_HOT_TUNE 0 and 2 (the default: one numbering for the view, one copy per band) at 64 spp (the calibration only runs from 64 samples per call on): the
     renumbering of the LDS candidates must leave a device-built tree's results alone -- same buffer bit for bit, same
     counts, the same closest-hit records before and after the renumbering -- and its premise is checked on the records
     themselves: parents carry lower numbers than their children, so no record behind the candidates refers into them."""
@@ -250,7 +250,7 @@ def test_hot_node_tuning_on_a_device_built_tree_moves_records_not_results():
     rays = np.concatenate([orc.primary_rays(orc.make_params(cfg, SEED, 16), 0)[::2], random_rays(np.random.RandomState(5), 8000, -150.0, 150.0)])
     npix = cfg.width * cfg.height
     out = {}
-    for tune in (0, 1):
+    for tune in (0, 2):
         ctx = capi.Context(0)
         try:
             ctx.set_option(capi.OPT_GPU_BVH, 1)
@@ -269,7 +269,7 @@ def test_hot_node_tuning_on_a_device_built_tree_moves_records_not_results():
             ctx.reset_counters()
             ctx.raytrace(npix, 0, 64, 16, cfg.max_depth, cfg.background, cfg.russian_roulette, d.data_ptr())
             cnt = ctx.counters()
-            after = _hits(ctx, rays)                                              # on the renumbered records when tune == 1
+            after = _hits(ctx, rays)                                              # on the renumbered records when tune != 0
             for a, b in zip(before, after):
                 assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
             order = ctx.check_node_numbering()
@@ -277,7 +277,7 @@ def test_hot_node_tuning_on_a_device_built_tree_moves_records_not_results():
             out[tune] = (d.cpu().numpy(), cnt, before)
         finally:
             ctx.close()
-    (a, ca, ha), (b, cb, hb) = out[0], out[1]
+    (a, ca, ha), (b, cb, hb) = out[0], out[2]
     assert same_f32(a, b), f"{(bits(a) != bits(b)).any(axis=1).sum()} pixels differ between tuned and untuned numbering"
     for k in (capi.CNT_RAYS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS):
         assert ca[k] == cb[k], k

@@ -601,30 +601,33 @@ def test_stress_scene_at_its_real_size(gpu_ctx):
 
 def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
     """The calibration pass (one sample per pixel counted into a visit histogram, the 4096 records nearest the root
-    renumbered by falling count) only moves records: same image, same counts, and more node visits served from LDS."""
+    renumbered by falling count -- RT_OPT_HOT_TUNE 1 -- and a copy of them numbered for every band of the picture -- 2)
+    only moves records: same image, same counts, and more node visits served from LDS."""
     asm = scene.formula1(width=200, height=120, n_samples=64, detail=0.15, tex_size=64)
     gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
     gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 18)
     try:
         out = {}
-        for tune in (0, 1):
+        for tune in (0, 1, 2):
             gpu_ctx.set_option(capi.OPT_HOT_TUNE, tune)
             p = Pair(gpu_ctx, asm)                                  # uploads again: the static numbering is back
             out[tune] = p.gpu_render(0, 64, 16)
             if tune:
                 again = p.gpu_render(0, 64, 16)                     # second frame, same camera: no new calibration, same picture
-                assert same_f32(again[0], out[1][0])
+                assert same_f32(again[0], out[tune][0])
                 hits_tuned = p.check_hits(orc.primary_rays(orc.make_params(p.cfg, SEED, 16), 0))     # rt_closest_hit on the renumbered records
                 assert (hits_tuned >= 0).any()
     finally:
-        gpu_ctx.set_option(capi.OPT_HOT_TUNE, 1)
+        gpu_ctx.set_option(capi.OPT_HOT_TUNE, 2)
         gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
         gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
-    (a, ca), (b, cb) = out[0], out[1]
-    assert same_f32(a, b)
+    (a, ca), (b, cb), (c, cc) = out[0], out[1], out[2]
+    assert same_f32(a, b) and same_f32(a, c)
     for k in (capi.CNT_RAYS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS, capi.CNT_NODE_VISITS):
-        assert ca[k] == cb[k], k
-    assert cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
+        assert ca[k] == cb[k] == cc[k], k
+    # one numbering for the view beats the static one; a numbering per band of the picture (two bands at 120 rows, in a pool
+    # of 2^18 entries that holds a sixth of the pass) beats that
+    assert cc[capi.CNT_HOT_VISITS] > cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
 
 
 def test_library_defaults_all_at_once_against_the_oracle():
