@@ -439,7 +439,7 @@ def main():
             top = l1_key if (kname == "wf_extend_kernel" and l1_key in roofs) else busiest
             binding = {"roof": top, "frac": roofs[top], "busiest_unit": busiest, "all": roofs,
                        "why": ("vector issue is the busier unit, but removing 8-10 of ~85 vector instructions per node visit changed the kernel's time by "
-                               "0.3 %; the vector L1 charges every ACTIVE lane one clock (microbenchmark tools/microbench/l1_lanes.hip: 19/34/49/64 "
+                               "0.3 % and adding 16 changed it by nothing; the vector L1 charges every ACTIVE lane one clock (microbenchmark tools/microbench/l1_lanes.hip: 19/34/49/64 "
                                "clocks per wave-level load with 16/32/48/64 lanes), hits included, and is what the waves queue for -- four neighbouring "
                                "lanes that ask for one address are served in one clock, which is why tracing the samples of a batch (identical "
                                "primary rays) in neighbouring lanes took 17 % of the accesses per ray away and added 10.5 % to the rate")
