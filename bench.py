@@ -412,7 +412,7 @@ def main():
         traffic = kp.get("hbm_bytes_per_launch")
         # the counter passes ran the same command; their launch time (profiled clocks run ~3 % lower) prices their bytes
         traffic_gbps = traffic / (kp["kernel_ms_mean"] * 1e-3) / 1e9 if traffic and kp.get("kernel_ms_mean") else None
-        # the survey's per-ray figure (box and triangle reads of the walk, shading records and texels of the hits): what the
+        # the per-ray demand figure in full (box and triangle reads of the walk, shading records and texels of the hits): what the
         # path asks of the memory hierarchy, priced against HBM although LDS, L1, L2 and Infinity Cache serve nearly all of it
         survey_gbps = walks_per_launch * bytes_per_ray / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         other_workloads = {}
