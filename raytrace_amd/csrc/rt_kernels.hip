@@ -1681,7 +1681,8 @@ static int tune_hot_nodes(rt_context* ctx, PathParams pp, hipStream_t s) {
     pp.n_pixel = pp.cam.width * pp.cam.height;
     pp.tiles_x = (pp.cam.width + 15) / 16;
     pp.tiles_y = (pp.cam.height + 15) / 16;
-    uint32_t bands = ctx->opt_hot_tune >= 2 ? std::min<uint32_t>(RT_BANDS_MAX, (uint32_t)pp.tiles_y) : 1u;
+    // a band's numbering is as good as its share of the calibration's paths: at least 2048 of them per band, or fewer bands
+    uint32_t bands = ctx->opt_hot_tune >= 2 ? std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(RT_BANDS_MAX, (uint32_t)pp.tiles_y), (uint32_t)pp.n_pixel / 2048u)) : 1u;
     const size_t hist_bytes = (size_t)RT_BANDS_MAX * RT_HIST_NODES * sizeof(uint32_t), cnt_bytes = RT_CNT_WORDS * sizeof(unsigned long long);
     const size_t perm_at = hist_bytes + cnt_bytes, copy_at = perm_at + hist_bytes;       // the permutations take as much room as the counts
     if (!ctx->d_tune) HIP_TRY(hipMalloc(&ctx->d_tune, copy_at + RT_HIST_NODES * sizeof(Node4)));

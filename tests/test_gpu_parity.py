@@ -625,9 +625,48 @@ def test_hot_node_tuning_changes_numbers_not_results(gpu_ctx):
     assert same_f32(a, b) and same_f32(a, c)
     for k in (capi.CNT_RAYS, capi.CNT_BOX_TESTS, capi.CNT_TRI_TESTS, capi.CNT_SHADED, capi.CNT_TEX_FETCHES, capi.CNT_PATHS, capi.CNT_NODE_VISITS):
         assert ca[k] == cb[k] == cc[k], k
-    # one numbering for the view beats the static one; a numbering per band of the picture (two bands at 120 rows, in a pool
-    # of 2^18 entries that holds a sixth of the pass) beats that
-    assert cc[capi.CNT_HOT_VISITS] > cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
+    # one numbering for the view beats the static one; a frame this small has too few calibration paths for bands of its
+    # own (2048 per band are asked for), so the third setting falls back to the second
+    assert cc[capi.CNT_HOT_VISITS] == cb[capi.CNT_HOT_VISITS] > ca[capi.CNT_HOT_VISITS]
+
+
+def test_band_copies_follow_the_camera_and_the_passes(gpu_ctx):
+    """The per-band copies of the first node records (RT_OPT_HOT_TUNE 2) belong to one scene and one camera.  A tall frame
+    (nine bands of the 100x200 calibration frame) in a pool that holds a fortieth of a pass, in passes of 64 samples: rendered, then the camera moves (the
+    copies must be dropped and made again, or the launches would read records numbered for another view -- harmless to the
+    bits, but the test also checks that the calibration ran again), then the setting goes 2 -> 1 -> 2 on the same scene.
+    Every render against the oracle; LDS-served visits with the copies above those without."""
+    import copy
+    asm = scene.formula1(width=400, height=800, n_samples=128, detail=0.1, tex_size=32)
+    gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_WAVEFRONT)
+    gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 19)
+    gpu_ctx.set_option(capi.OPT_PASS, 64)
+    try:
+        p = Pair(gpu_ctx, asm)
+        params = orc.make_params(p.cfg, SEED, 16)
+        ref, rcnt = p.oracle.render(params, 0, 128)
+        got, cnt2 = p.gpu_render(0, 128, 16)
+        assert same_f32(got, ref) and cnt2[capi.CNT_RAYS] == rcnt[0] and cnt2[capi.CNT_TRI_TESTS] == rcnt[2]
+        # another view of the same scene
+        cfg2 = copy.copy(p.cfg)
+        cfg2.camera_pos = (p.cfg.camera_pos[0] * 0.8, p.cfg.camera_pos[1] + 40.0, p.cfg.camera_pos[2] * 1.1)
+        gpu_ctx.setup_raytrace(cfg2.width, cfg2.height, cfg2.camera_pos, cfg2.camera_dir, cfg2.camera_up, cfg2.fov)
+        ref2, rcnt2 = p.oracle.render(orc.make_params(cfg2, SEED, 16), 0, 128)
+        got2, cnt = p.gpu_render(0, 128, 16)
+        assert same_f32(got2, ref2) and cnt[capi.CNT_RAYS] == rcnt2[0] and cnt[capi.CNT_TRI_TESTS] == rcnt2[2]
+        hot = {}
+        for tune in (1, 2):
+            gpu_ctx.set_option(capi.OPT_HOT_TUNE, tune)
+            again, c = p.gpu_render(0, 128, 16)
+            assert same_f32(again, ref2), tune
+            assert c[capi.CNT_NODE_VISITS] == cnt[capi.CNT_NODE_VISITS] and c[capi.CNT_BOX_TESTS] == cnt[capi.CNT_BOX_TESTS]
+            hot[tune] = c[capi.CNT_HOT_VISITS]
+        assert hot[2] > hot[1] and abs(hot[2] - cnt[capi.CNT_HOT_VISITS]) <= 0.01 * hot[2]       # made again, and the same again (up to ties)
+    finally:
+        gpu_ctx.set_option(capi.OPT_HOT_TUNE, 2)
+        gpu_ctx.set_option(capi.OPT_PASS, 1024)
+        gpu_ctx.set_option(capi.OPT_MODE, capi.MODE_MEGAKERNEL)
+        gpu_ctx.set_option(capi.OPT_WF_CAPACITY_LOG2, 20)
 
 
 def test_library_defaults_all_at_once_against_the_oracle():
