@@ -30,7 +30,8 @@ typedef enum rt_status {
     RT_ERR_DEVICE = -2,       /* HIP runtime error */
     RT_ERR_NO_SCENE = -3,     /* call needs rt_upload_scene first */
     RT_ERR_NO_CAMERA = -4,    /* call needs rt_setup_raytrace first */
-    RT_ERR_CAPACITY = -5      /* caller buffer too small */
+    RT_ERR_CAPACITY = -5,     /* caller buffer too small */
+    RT_ERR_HOST = -6          /* the host side of a call failed: out of host memory, no thread to be had (no C++ exception leaves the library) */
 } rt_status;
 
 /* ---- PODs in the upstream host layout (so upstream arrays pass unchanged) ---- */

@@ -25,6 +25,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1029,6 +1030,21 @@ static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
 
+// No C++ exception may leave through the C ABI (a caller in C, Go or Python could not catch it): the entry points that
+// allocate host memory in proportion to the scene, or start threads, run their bodies through this.
+template <class Body>
+static int guarded(const char* who, Body&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_HOST, std::string(who) + ": out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_HOST, std::string(who) + ": " + e.what());
+    } catch (...) {
+        return fail(RT_ERR_HOST, std::string(who) + ": unknown exception");
+    }
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -1162,11 +1178,13 @@ int rt_abi_version(void) { return RTCORE_ABI_VERSION; }
 
 int rt_build_bvh(const rt_triangle* triangles, int n_triangles, rt_bvh_node* nodes_out, int capacity) {
     if (!triangles || !nodes_out || n_triangles <= 0) return fail(RT_ERR_INVALID, "rt_build_bvh: null array or n_triangles <= 0");
-    std::vector<rt_bvh_node> nodes;
-    const int n = build_bvh(triangles, n_triangles, nodes);
-    if (n > capacity) return fail(RT_ERR_CAPACITY, "rt_build_bvh: need " + std::to_string(n) + " nodes");
-    std::memcpy(nodes_out, nodes.data(), (size_t)n * sizeof(rt_bvh_node));
-    return n;
+    return guarded("rt_build_bvh", [&]() -> int {
+        std::vector<rt_bvh_node> nodes;
+        const int n = build_bvh(triangles, n_triangles, nodes);
+        if (n > capacity) return fail(RT_ERR_CAPACITY, "rt_build_bvh: need " + std::to_string(n) + " nodes");
+        std::memcpy(nodes_out, nodes.data(), (size_t)n * sizeof(rt_bvh_node));
+        return n;
+    });
 }
 
 int rt_apply_transform(const rt_transform* transform, rt_triangle* triangles, int n_triangles) {
@@ -1278,8 +1296,16 @@ int rt_set_option(rt_context* ctx, int option, int value) {
     }
 }
 
+static int upload_scene_body(rt_context* ctx, const rt_object* objects, int n_objects, const rt_material* materials, int n_materials,
+                             const rt_texture* textures, int n_textures);
+
 int rt_upload_scene(rt_context* ctx, const rt_object* objects, int n_objects, const rt_material* materials, int n_materials,
                     const rt_texture* textures, int n_textures) {
+    return guarded("rt_upload_scene", [&]() -> int { return upload_scene_body(ctx, objects, n_objects, materials, n_materials, textures, n_textures); });
+}
+
+static int upload_scene_body(rt_context* ctx, const rt_object* objects, int n_objects, const rt_material* materials, int n_materials,
+                             const rt_texture* textures, int n_textures) {
     if (!ctx || !objects || n_objects <= 0 || !materials || n_materials <= 0 || n_textures < 0 || (n_textures > 0 && !textures))
         return fail(RT_ERR_INVALID, "rt_upload_scene: bad argument");
     // every material id and texture index must be in range: the kernels index with them unchecked
@@ -1885,8 +1911,10 @@ static int raytrace_body(const char* who, rt_context* ctx, int n_pixel, int firs
 
 int rt_raytrace(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
                 float russian_roulette, float* d_output, void* stream) {
-    return raytrace_body("rt_raytrace", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, russian_roulette, d_output,
-                         (hipStream_t)stream, nullptr, 0);
+    return guarded("rt_raytrace", [&]() -> int {
+        return raytrace_body("rt_raytrace", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, ambient, russian_roulette, d_output,
+                             (hipStream_t)stream, nullptr, 0);
+    });
 }
 
 int rt_raytrace_start(rt_context* ctx, int n_pixel, int first_sample, int spp, int semantic_batch, int max_depth, const float ambient[3],
@@ -1898,13 +1926,15 @@ int rt_raytrace_start(rt_context* ctx, int n_pixel, int first_sample, int spp, i
     ctx->job_error.clear();
     try {
         ctx->job = std::thread([=]() {
-            const int rc = raytrace_body("rt_raytrace_start", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, amb, russian_roulette,
-                                         d_output, (hipStream_t)stream, nullptr, 0);
+            const int rc = guarded("rt_raytrace_start", [&]() -> int {
+                return raytrace_body("rt_raytrace_start", ctx, n_pixel, first_sample, spp, semantic_batch, max_depth, amb, russian_roulette,
+                                     d_output, (hipStream_t)stream, nullptr, 0);
+            });
             ctx->job_status = rc;
             if (rc != RT_OK) ctx->job_error = g_last_error;       // the error text is per thread: hand it to the one that waits
         });
     } catch (const std::exception& e) {
-        return fail(RT_ERR_DEVICE, std::string("rt_raytrace_start: cannot start a thread: ") + e.what());
+        return fail(RT_ERR_HOST, std::string("rt_raytrace_start: cannot start a thread: ") + e.what());
     }
     return RT_OK;
 }
@@ -2006,23 +2036,25 @@ int rt_scene_stats(rt_context* ctx, uint64_t out[8]) {
 int rt_check_node_numbering(rt_context* ctx, uint64_t out[8]) {
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_check_node_numbering: null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_check_node_numbering: no scene uploaded");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipDeviceSynchronize());
-    const uint64_t n = ctx->stats[1];
-    std::vector<Node4> nodes(n);
-    if (n) HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, n * sizeof(Node4), hipMemcpyDeviceToHost));
-    const uint64_t k = std::min<uint64_t>(RT_HIST_NODES, n);
-    for (int i = 0; i < 8; i++) out[i] = 0;
-    out[0] = n; out[1] = k;
-    for (uint64_t i = 0; i < n; i++)
-        for (int slot = 0; slot < 4; slot++) {
-            const uint32_t r = nodes[i].ref[slot];
-            if (r == REF_NONE || (r & REF_LEAF)) continue;
-            if (i >= k && r < k) out[2]++;
-            if (r >= n) out[3]++;
-            if (r <= i) out[4]++;
-        }
-    return RT_OK;
+    return guarded("rt_check_node_numbering", [&]() -> int {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        const uint64_t n = ctx->stats[1];
+        std::vector<Node4> nodes(n);
+        if (n) HIP_TRY(hipMemcpy(nodes.data(), ctx->d_nodes, n * sizeof(Node4), hipMemcpyDeviceToHost));
+        const uint64_t k = std::min<uint64_t>(RT_HIST_NODES, n);
+        for (int i = 0; i < 8; i++) out[i] = 0;
+        out[0] = n; out[1] = k;
+        for (uint64_t i = 0; i < n; i++)
+            for (int slot = 0; slot < 4; slot++) {
+                const uint32_t r = nodes[i].ref[slot];
+                if (r == REF_NONE || (r & REF_LEAF)) continue;
+                if (i >= k && r < k) out[2]++;
+                if (r >= n) out[3]++;
+                if (r <= i) out[4]++;
+            }
+        return RT_OK;
+    });
 }
 
 int rt_device_alloc(rt_context* ctx, uint64_t bytes, void** d_ptr) {
